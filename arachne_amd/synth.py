@@ -1,0 +1,214 @@
+"""Synthetic linked-read workloads: genomes with planted repeat families and
+paired 2x150 bp haplotagging-style reads grouped by BX barcode.
+
+There is no network on the GPU box, so bench.py and the tests synthesise inputs of the shape
+BASELINE.json names.  Everything is seeded (seed = 20250905 + config#) and vectorised with numpy.
+
+Encoding used throughout the package: bases are uint8 0..3 = A,C,G,T and 4 = N (the reference's
+nst_nt4_table, /root/reference/src/gobwa/bwa/bntseq.c:47).
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+BASES = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+@dataclasses.dataclass
+class Genome:
+    names: list          # contig names
+    seqs: list           # list of uint8 arrays (0..4)
+    alt: list            # bool per contig (goes to the .alt file)
+
+    @property
+    def total_len(self) -> int:
+        return int(sum(len(s) for s in self.seqs))
+
+    def write_fasta(self, path: str, width: int = 80) -> None:
+        with open(path, "wb") as f:
+            for name, s in zip(self.names, self.seqs):
+                f.write(b">" + name.encode() + b"\n")
+                asc = BASES[s]
+                n = len(asc)
+                full = (n // width) * width
+                if full:
+                    body = np.empty((n // width, width + 1), dtype=np.uint8)
+                    body[:, :width] = asc[:full].reshape(-1, width)
+                    body[:, width] = 10
+                    f.write(body.tobytes())
+                if n > full:
+                    f.write(asc[full:].tobytes() + b"\n")
+
+    def write_alt(self, path: str) -> None:
+        with open(path, "w") as f:
+            for name, a in zip(self.names, self.alt):
+                if a:
+                    f.write(name + "\n")
+
+
+def _mutate(rng, s, div):
+    s = s.copy()
+    m = rng.random(len(s)) < div
+    k = int(m.sum())
+    if k:
+        s[m] = (s[m] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+    return s
+
+
+def make_genome(seed: int, contig_lens, repeat_families=None, n_runs: int = 2, alt_contigs: int = 0) -> Genome:
+    """Uniform ACGT contigs + planted repeat families + runs of N.
+
+    repeat_families: list of (copies, length, divergence); defaults scale the SURVEY §8d recipe
+    (Alu-like 300 bp @12%, L1-like 6 kb @5%, segmental duplications 50 kb @1%) to the genome size.
+    """
+    rng = np.random.default_rng(seed)
+    total = int(sum(contig_lens))
+    seqs = [rng.integers(0, 4, size=int(L), dtype=np.uint8) for L in contig_lens]
+    if repeat_families is None:
+        scale = total / 3.1e9
+        repeat_families = [
+            (max(4, int(1e4 * scale * 20)), 300, 0.12),
+            (max(3, int(1e3 * scale * 20)), 6000, 0.05),
+            (max(2, int(200 * scale * 10)), 50000, 0.01),
+        ]
+    for copies, length, div in repeat_families:
+        length = int(min(length, min(contig_lens) // 4))
+        if length < 50:
+            continue
+        tmpl = rng.integers(0, 4, size=length, dtype=np.uint8)
+        for _ in range(int(copies)):
+            ci = int(rng.integers(0, len(seqs)))
+            if len(seqs[ci]) <= length + 2:
+                continue
+            p = int(rng.integers(0, len(seqs[ci]) - length))
+            c = _mutate(rng, tmpl, div)
+            if rng.random() < 0.5:
+                c = (3 - c)[::-1]
+            seqs[ci][p:p + length] = c
+    for ci in range(len(seqs)):
+        for _ in range(n_runs):
+            L = len(seqs[ci])
+            if L < 5000:
+                continue
+            ln = int(rng.integers(20, 400))
+            p = int(rng.integers(0, L - ln))
+            seqs[ci][p:p + ln] = 4
+    names = [f"chrS{i + 1}" for i in range(len(seqs))]
+    alt = [False] * len(seqs)
+    for k in range(alt_contigs):
+        # ALT contig = diverged copy of a slice of a primary contig
+        src = seqs[k % len(seqs)]
+        ln = int(min(20000, len(src) // 3))
+        p = int(rng.integers(0, len(src) - ln))
+        a = _mutate(rng, src[p:p + ln], 0.02)
+        a[a > 3] = 0
+        seqs.append(a)
+        names.append(f"chrS{(k % len(contig_lens)) + 1}_alt{k + 1}")
+        alt.append(True)
+    return Genome(names, seqs, alt)
+
+
+@dataclasses.dataclass
+class ReadSet:
+    seqs: np.ndarray       # (2*n_pairs, read_len) uint8 0..4; row 2i = R1, 2i+1 = R2
+    lens: np.ndarray       # (2*n_pairs,) int32
+    barcode_id: np.ndarray  # (n_pairs,) int32 -> index into barcodes
+    barcodes: list         # barcode strings (contain '-' so that the reference runs RFA, aligner.go:1022)
+    valid: np.ndarray      # (n_pairs,) bool  -> VX:i:1 / VX:i:0
+    truth_contig: np.ndarray
+    truth_pos: np.ndarray  # leftmost 0-based position of the fragment on the contig
+
+    @property
+    def n_pairs(self) -> int:
+        return len(self.barcode_id)
+
+    def pair_offsets(self) -> np.ndarray:
+        """Offsets of each barcode group in pair units (pairs are stored grouped by barcode)."""
+        chg = np.flatnonzero(np.diff(self.barcode_id)) + 1
+        return np.concatenate([[0], chg, [self.n_pairs]]).astype(np.int64)
+
+
+def _revcomp(a):
+    r = a[..., ::-1].copy()
+    m = r < 4
+    r[m] = 3 - r[m]
+    return r
+
+
+def make_reads(seed: int, genome: Genome, n_barcodes: int, pairs_per_barcode: int, read_len: int = 150,
+               molecules_per_barcode: int = 10, molecule_len: int = 50000, sub_rate: float = 0.005,
+               indel_rate: float = 0.0002, invalid_frac: float = 0.0, repeat_bias=None) -> ReadSet:
+    """Pairs are FR, insert ~ N(350,50) clipped to >= read_len+10, drawn uniformly inside molecules."""
+    rng = np.random.default_rng(seed)
+    n_pairs = n_barcodes * pairs_per_barcode
+    clen = np.array([len(s) for s in genome.seqs], dtype=np.int64)
+    prim = np.array([not a for a in genome.alt])
+    cw = (clen * prim).astype(np.float64)
+    cw /= cw.sum()
+    cat = np.concatenate(genome.seqs)
+    coff = np.concatenate([[0], np.cumsum(clen)])[:-1]
+    # molecules
+    n_mol = n_barcodes * molecules_per_barcode
+    mol_c = rng.choice(len(clen), size=n_mol, p=cw)
+    mlen = np.minimum(molecule_len, clen[mol_c] - 1)
+    mol_s = (rng.random(n_mol) * (clen[mol_c] - mlen)).astype(np.int64)
+    bc = np.repeat(np.arange(n_barcodes, dtype=np.int32), pairs_per_barcode)
+    mol = bc.astype(np.int64) * molecules_per_barcode + rng.integers(0, molecules_per_barcode, size=n_pairs)
+    ins = np.clip(rng.normal(350, 50, size=n_pairs).astype(np.int64), read_len + 10, 800)
+    ins = np.minimum(ins, mlen[mol] - 1)
+    ins = np.maximum(ins, read_len)
+    fs = mol_s[mol] + (rng.random(n_pairs) * (mlen[mol] - ins)).astype(np.int64)
+    c = mol_c[mol]
+    g0 = coff[c] + fs
+    ar = np.arange(read_len, dtype=np.int64)
+    left = cat[g0[:, None] + ar[None, :]]
+    right = _revcomp(cat[(g0 + ins - read_len)[:, None] + ar[None, :]])
+    flip = rng.random(n_pairs) < 0.5           # which mate is read 1
+    r1 = np.where(flip[:, None], right, left)
+    r2 = np.where(flip[:, None], left, right)
+    seqs = np.empty((2 * n_pairs, read_len), dtype=np.uint8)
+    seqs[0::2] = r1
+    seqs[1::2] = r2
+    # substitutions
+    m = (rng.random(seqs.shape) < sub_rate) & (seqs < 4)
+    k = int(m.sum())
+    seqs[m] = (seqs[m] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+    # small indels (1-3 bp) on a sparse subset, keeping the read length fixed
+    if indel_rate > 0:
+        rows = np.flatnonzero(rng.random(2 * n_pairs) < indel_rate * read_len)
+        for r in rows:
+            p = int(rng.integers(10, read_len - 10))
+            ln = int(rng.integers(1, 4))
+            s = seqs[r]
+            if rng.random() < 0.5:  # deletion from the read
+                s[p:read_len - ln] = s[p + ln:]
+                s[read_len - ln:] = rng.integers(0, 4, size=ln, dtype=np.uint8)
+            else:                   # insertion into the read
+                s[p + ln:] = s[p:read_len - ln].copy()
+                s[p:p + ln] = rng.integers(0, 4, size=ln, dtype=np.uint8)
+    barcodes = []
+    alpha = "ABCD"
+    for b in range(n_barcodes):
+        x = b
+        parts = []
+        for seg in "ACBD":
+            parts.append(f"{seg}{(x % 96) + 1:02d}")
+            x //= 96
+        barcodes.append("".join(parts) + "-1")
+    valid = rng.random(n_pairs) >= invalid_frac
+    lens = np.full(2 * n_pairs, read_len, dtype=np.int32)
+    return ReadSet(seqs, lens, bc, barcodes, valid, c.astype(np.int32), fs)
+
+
+def write_fastq(rs: ReadSet, path1: str, path2: str) -> None:
+    """Barcode-sorted FASTQ pair in the header format the reference's reader parses
+    (/root/reference/src/fastqreader/reader.go:95-153): '@name/1\\tBX:Z:<bc>\\tVX:i:<0|1>'."""
+    with open(path1, "w") as f1, open(path2, "w") as f2:
+        for i in range(rs.n_pairs):
+            bcs = rs.barcodes[rs.barcode_id[i]]
+            vx = 1 if rs.valid[i] else 0
+            for f, row, mate in ((f1, 2 * i, 1), (f2, 2 * i + 1, 2)):
+                L = int(rs.lens[row])
+                s = BASES[rs.seqs[row, :L]].tobytes().decode()
+                f.write(f"@r{i}/{mate}\tBX:Z:{bcs}\tVX:i:{vx}\n{s}\n+\n{'I' * L}\n")
