@@ -1,0 +1,204 @@
+"""Host-side binding of libarachne_amd.so (ctypes over the C ABI of include/arachne_amd.h).
+
+The names mirror the reference's Go bridge (/root/reference/src/gobwa/gobwa.go) so that tests read like its
+call sites: `load_reference` ~ GoBwaLoadReference (:128), `Reference.contigs` ~ GetReferenceContigsInfo (:28),
+`sequence_convert` ~ SequenceConvert (:159), `Reference.mem_mate_sw` ~ GoBwaMemMateSW (:226) for a whole batch of
+pairs followed by GoBwaSmithWaterman (:400) for every candidate.
+
+The library is the product path and it is the only path: if the shared object is missing, or no MI355X is
+visible, loading / opening raises -- there is no CPU fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarachne_amd.so")
+
+REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"),
+                      ("sub", "<i4"), ("alt_sc", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"), ("seedcov", "<i4"),
+                      ("secondary", "<i4"), ("secondary_all", "<i4"), ("seedlen0", "<i4"), ("n_comp", "<i4"), ("is_alt", "<i4"),
+                      ("frac_rep", "<f4"), ("pad", "<i4")])
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev", "<i4"), ("is_alt", "<i4"), ("NM", "<i4"),
+                      ("n_cigar", "<i4"), ("cigar_off", "<i4"), ("score", "<i4"), ("sub", "<i4"), ("alt_sc", "<i4")])
+CHAIN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n", "<i4"), ("seed_off", "<i4"), ("w", "<i4"), ("kept", "<i4"), ("first", "<i4"),
+                        ("is_alt", "<i4"), ("head", "<i4"), ("tail", "<i4"), ("frac_rep", "<f4")])
+SEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+CAP_INTV = 256
+STAGE_SEED, STAGE_CHAIN, STAGE_EXTEND, STAGE_RESCUE, STAGE_ALN = 1, 2, 3, 4, 5
+
+_NT4 = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _NT4[ord(_c)] = _i
+    _NT4[ord(_c.lower())] = _i
+
+
+def sequence_convert(seq) -> np.ndarray:
+    """ASCII bases -> codes 0..4 (nst_nt4_table; '-' is not special-cased on this path)."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    return _NT4[np.frombuffer(seq, dtype=np.uint8)]
+
+
+class ArachneError(RuntimeError):
+    pass
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise ArachneError(f"{path} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.arx_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.arx_close.argtypes = [vp]
+    lib.arx_last_error.restype = C.c_char_p
+    lib.arx_last_error.argtypes = [vp]
+    lib.arx_backend.restype = C.c_char_p
+    lib.arx_contigs.argtypes = [vp] + [vp] * 6
+    lib.arx_batch_create.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
+    lib.arx_batch_run.argtypes = [vp, vp, i32]
+    lib.arx_batch_counts.argtypes = [vp, vp, vp]
+    lib.arx_batch_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.arx_batch_free.argtypes = [vp, vp]
+    lib.arx_batch_debug_intv.argtypes = [vp, vp, vp, vp]
+    lib.arx_batch_debug_chains.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.arx_batch_debug_core.argtypes = [vp, vp, vp, vp]
+    lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    lib.arx_kernel_times_reset.argtypes = [vp, i32]
+    return lib
+
+
+class Batch:
+    """One batch of read pairs resident on the device (arx_batch)."""
+
+    def __init__(self, ref: "Reference", seqs, lens):
+        self.ref = ref
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        bases = np.ascontiguousarray(seqs, dtype=np.uint8).reshape(-1)
+        if bases.size != int(lens.sum()):
+            raise ArachneError("bases do not match lens")
+        self.n_reads = len(lens)
+        self._keep = (bases, lens)
+        h = C.c_void_p()
+        ref._check(ref.lib.arx_batch_create(ref.h, self.n_reads, bases.ctypes.data, lens.ctypes.data, C.byref(h)))
+        self.h = h
+
+    def run(self, last_stage=STAGE_ALN):
+        self.ref._check(self.ref.lib.arx_batch_run(self.ref.h, self.h, last_stage))
+        return self
+
+    def counts(self):
+        c = np.zeros(8, dtype=np.int64)
+        self.ref._check(self.ref.lib.arx_batch_counts(self.ref.h, self.h, c.ctypes.data))
+        return dict(zip(["n_reads", "n_regs", "n_cigar", "n_occ", "ext_rounds", "n_ext", "rescue_rounds", "n_sw"], c.tolist()))
+
+    def fetch(self):
+        c = self.counts()
+        reg_off = np.zeros(self.n_reads + 1, dtype=np.int32)
+        regs = np.zeros(c["n_regs"], dtype=REG_DTYPE)
+        alns = np.zeros(c["n_regs"], dtype=ALN_DTYPE)
+        cig = np.zeros(max(c["n_cigar"], 1), dtype=np.uint32)
+        self.ref._check(self.ref.lib.arx_batch_fetch(self.ref.h, self.h, reg_off.ctypes.data, regs.ctypes.data, alns.ctypes.data, cig.ctypes.data))
+        return dict(reg_off=reg_off, regs=regs, alns=alns, cigars=cig[:c["n_cigar"]], counts=c)
+
+    def debug_intv(self):
+        n = np.zeros(self.n_reads, dtype=np.int32)
+        iv = np.zeros((self.n_reads, CAP_INTV, 4), dtype=np.uint64)
+        self.ref._check(self.ref.lib.arx_batch_debug_intv(self.ref.h, self.h, n.ctypes.data, iv.ctypes.data))
+        return n, iv
+
+    def debug_chains(self):
+        T = self.counts()["n_occ"]
+        off = np.zeros(self.n_reads + 1, dtype=np.int32)
+        n = np.zeros(self.n_reads, dtype=np.int32)
+        ch = np.zeros(max(T, 1), dtype=CHAIN_DTYPE)
+        sd = np.zeros(max(T, 1), dtype=SEED_DTYPE)
+        self.ref._check(self.ref.lib.arx_batch_debug_chains(self.ref.h, self.h, off.ctypes.data, n.ctypes.data, ch.ctypes.data, sd.ctypes.data))
+        return off, n, ch, sd
+
+    def debug_core(self):
+        T = self.counts()["n_occ"]
+        n = np.zeros(self.n_reads, dtype=np.int32)
+        rg = np.zeros(max(T, 1), dtype=REG_DTYPE)
+        self.ref._check(self.ref.lib.arx_batch_debug_core(self.ref.h, self.h, n.ctypes.data, rg.ctypes.data))
+        return n, rg
+
+    def free(self):
+        if self.h:
+            self.ref.lib.arx_batch_free(self.ref.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Reference:
+    """A loaded index resident in HBM (arx_ctx); mirrors gobwa.GoBwaReference + GoBwaSettings."""
+
+    def __init__(self, prefix: str, device: int = 0, lib_path: str = LIB_PATH):
+        self.lib = _load(lib_path)
+        self.h = C.c_void_p()
+        rc = self.lib.arx_open(prefix.encode(), device, C.byref(self.h))
+        if rc != 0:
+            msg = self.lib.arx_last_error(None).decode()
+            self.h = None
+            raise ArachneError(f"arx_open({prefix}) failed: {msg}")
+        self.backend = self.lib.arx_backend().decode()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ArachneError(f"libarachne_amd error {rc}: {self.lib.arx_last_error(self.h).decode()}")
+
+    def contigs(self):
+        """-> (names, offsets, lengths, is_alt, l_pac)"""
+        n = C.c_int32()
+        names = C.POINTER(C.c_char_p)()
+        offs = C.POINTER(C.c_int64)()
+        lens = C.POINTER(C.c_int32)()
+        alt = C.POINTER(C.c_int32)()
+        lp = C.c_int64()
+        self._check(self.lib.arx_contigs(self.h, C.byref(n), C.byref(names), C.byref(offs), C.byref(lens), C.byref(alt), C.byref(lp)))
+        k = n.value
+        return ([names[i].decode() for i in range(k)], [offs[i] for i in range(k)], [lens[i] for i in range(k)], [alt[i] for i in range(k)], lp.value)
+
+    def batch(self, seqs, lens) -> Batch:
+        return Batch(self, seqs, lens)
+
+    def mem_mate_sw(self, seqs, lens):
+        """Whole hot path for a batch of pairs (rows 2i / 2i+1 are mates): candidate regions of both reads after
+        mate rescue and the alignment record (pos, strand, NM, CIGAR) of every candidate."""
+        b = self.batch(seqs, lens)
+        try:
+            return b.run().fetch()
+        finally:
+            b.free()
+
+    def kernel_times(self, cap=64):
+        names = C.create_string_buffer(cap * 32)
+        ms = np.zeros(cap, dtype=np.float64)
+        calls = np.zeros(cap, dtype=np.int64)
+        items = np.zeros(cap, dtype=np.int64)
+        n = self.lib.arx_kernel_times(self.h, cap, names, 32, ms.ctypes.data, calls.ctypes.data, items.ctypes.data)
+        out = {}
+        for i in range(n):
+            nm = names.raw[i * 32:(i + 1) * 32].split(b"\0")[0].decode()
+            out[nm] = dict(ms=float(ms[i]), calls=int(calls[i]), items=int(items[i]))
+        return out
+
+    def kernel_times_reset(self, enable=True):
+        self.lib.arx_kernel_times_reset(self.h, int(enable))
+
+    def close(self):
+        if self.h:
+            self.lib.arx_close(self.h)
+            self.h = None
+
+
+def load_reference(prefix: str, device: int = 0) -> Reference:
+    return Reference(prefix, device)

@@ -1,0 +1,168 @@
+// api_impl.h -- implementation of the C-ABI declared in include/arachne_amd.h on top of Pipeline<RT>.
+// The product build (arx_api.hip) instantiates it with HipRT.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include "../../include/arachne_amd.h"
+#include "index_io.h"
+#include "pipeline.h"
+
+namespace arx {
+
+template <class RT> struct Context {
+	RT rt;
+	HostIndex hix;
+	IndexView ix;
+	std::vector<void *> dev_index;
+	std::string last_error;
+	std::vector<const char *> name_ptrs;
+
+	std::string open(const std::string &prefix, int device)
+	{
+		std::string e = rt.init(device);
+		if (!e.empty()) return e;
+		e = load_index(prefix, hix);
+		if (!e.empty()) return e;
+		auto up = [&](const void *src, size_t bytes) { void *d = rt.template alloc<uint8_t>(bytes + 64); rt.h2d(d, src, bytes); dev_index.push_back(d); return d; };
+		ix.bwt = (const uint32_t *)up(hix.bwt.data(), hix.bwt.size() * 4);
+		ix.sa = (const uint64_t *)up(hix.sa.data(), hix.sa.size() * 8);
+		ix.pac = (const uint8_t *)up(hix.pac.data(), hix.pac.size());
+		ix.ann_off = (const int64_t *)up(hix.ann_off.data(), hix.ann_off.size() * 8);
+		ix.ann_len = (const int32_t *)up(hix.ann_len.data(), hix.ann_len.size() * 4);
+		ix.ann_alt = (const int32_t *)up(hix.ann_alt.data(), hix.ann_alt.size() * 4);
+		ix.primary = hix.primary; ix.seq_len = hix.seq_len;
+		for (int i = 0; i < 5; ++i) ix.L2[i] = hix.L2[i];
+		ix.l_pac = hix.l_pac; ix.n_seqs = (int)hix.names.size(); ix.sa_intv = hix.sa_intv;
+		for (auto &n : hix.names) name_ptrs.push_back(n.c_str());
+		return "";
+	}
+	~Context() { for (void *p : dev_index) rt.free(p); }
+};
+
+template <class RT> struct Batch {
+	Context<RT> *ctx;
+	Pipeline<RT> pipe;
+	typename Pipeline<RT>::DeviceBatch db;
+	typename Pipeline<RT>::Work work;
+	BatchResult res;
+	bool downloaded = false;
+	Batch(Context<RT> *c) : ctx(c), pipe(c->rt, c->ix) {}
+	~Batch() { pipe.free_work(work); pipe.release(db); }
+};
+
+} // namespace arx
+
+#define ARX_DEFINE_C_API(RT)                                                                                                        \
+	using Ctx = arx::Context<RT>;                                                                                                   \
+	using Bat = arx::Batch<RT>;                                                                                                     \
+	static thread_local std::string g_open_error;                                                                                   \
+	extern "C" {                                                                                                                    \
+	int arx_open(const char *prefix, int device, arx_ctx **out)                                                                     \
+	{                                                                                                                               \
+		*out = 0;                                                                                                                   \
+		Ctx *c = new Ctx();                                                                                                         \
+		std::string e = c->open(prefix, device);                                                                                    \
+		if (!e.empty()) { g_open_error = e; delete c; return ARX_E_OPEN; }                                                          \
+		*out = (arx_ctx *)c;                                                                                                        \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	void arx_close(arx_ctx *h) { delete (Ctx *)h; }                                                                                 \
+	const char *arx_last_error(arx_ctx *h) { return h ? ((Ctx *)h)->last_error.c_str() : g_open_error.c_str(); }                    \
+	const char *arx_backend(void) { return RT::name(); }                                                                            \
+	int arx_contigs(arx_ctx *h, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens,               \
+	                const int32_t **is_alt, int64_t *l_pac)                                                                         \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		*n = (int32_t)c->hix.names.size(); *names = c->name_ptrs.data(); *offsets = c->hix.ann_off.data();                          \
+		*lens = c->hix.ann_len.data(); *is_alt = c->hix.ann_alt.data(); *l_pac = c->hix.l_pac;                                      \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_create(arx_ctx *h, int32_t n_reads, const uint8_t *bases, const int32_t *lens, arx_batch **out)                   \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		*out = 0;                                                                                                                   \
+		if (n_reads <= 0 || (n_reads & 1)) { c->last_error = "n_reads must be positive and even (read 2i/2i+1 are mates)"; return ARX_E_ARG; } \
+		for (int i = 0; i < n_reads; ++i)                                                                                           \
+			if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->last_error = "read length outside [0, 249]"; return ARX_E_ARG; }   \
+		Bat *b = new Bat(c);                                                                                                        \
+		b->db = b->pipe.upload(bases, lens, n_reads);                                                                               \
+		*out = (arx_batch *)b;                                                                                                      \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_run(arx_ctx *h, arx_batch *bh, int32_t last_stage)                                                                \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->downloaded = false;                                             \
+		int rc = b->pipe.stage_seed(b->db, b->work);                                                                                \
+		if (rc == -2) { c->last_error = "batch too large: seed occurrences exceed 2^30, split the batch"; return ARX_E_TOO_LARGE; } \
+		b->res.n_occ = b->work.T;                                                                                                   \
+		if (last_stage >= ARX_STAGE_CHAIN) b->pipe.stage_chain(b->db, b->work);                                                     \
+		if (last_stage >= ARX_STAGE_EXTEND) b->pipe.stage_extend(b->db, b->work, b->res);                                           \
+		if (last_stage >= ARX_STAGE_RESCUE) b->pipe.stage_rescue(b->db, b->work, b->res);                                           \
+		uint32_t e = last_stage >= ARX_STAGE_ALN ? (uint32_t)b->pipe.stage_reg2aln(b->db, b->work) : b->pipe.read_err(b->work);     \
+		c->rt.sync();                                                                                                               \
+		if (e) { c->last_error = "device stage raised error bits " + std::to_string(e); return ARX_E_DEVICE; }                      \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_counts(arx_ctx *, arx_batch *bh, int64_t *c8)                                                                     \
+	{                                                                                                                               \
+		Bat *b = (Bat *)bh;                                                                                                         \
+		if (b->work.pregs && !b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                    \
+		c8[0] = b->db.n_reads; c8[1] = (int64_t)b->res.regs.size(); c8[2] = (int64_t)b->res.cigars.size(); c8[3] = b->res.n_occ;    \
+		c8[4] = b->res.ext_rounds; c8[5] = b->res.n_ext_tasks; c8[6] = b->res.rescue_rounds; c8[7] = b->res.n_sw_tasks;             \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_fetch(arx_ctx *, arx_batch *bh, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars)                 \
+	{                                                                                                                               \
+		Bat *b = (Bat *)bh;                                                                                                         \
+		if (!b->work.pregs) return ARX_E_ARG;                                                                                       \
+		if (!b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                                     \
+		static_assert(sizeof(arx_reg) == sizeof(arx::Reg) && sizeof(arx_aln) == sizeof(arx::Aln), "C-ABI structs must mirror the device structs"); \
+		memcpy(reg_off, b->res.reg_off.data(), 4 * b->res.reg_off.size());                                                          \
+		memcpy(regs, b->res.regs.data(), sizeof(arx::Reg) * b->res.regs.size());                                                    \
+		memcpy(alns, b->res.alns.data(), sizeof(arx::Aln) * b->res.alns.size());                                                    \
+		memcpy(cigars, b->res.cigars.data(), 4 * b->res.cigars.size());                                                             \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_debug_intv(arx_ctx *h, arx_batch *bh, int32_t *n_intv, uint64_t *intv4)                                           \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.intv) return ARX_E_ARG;                                                                                        \
+		c->rt.d2h(n_intv, b->work.n_intv, 4 * (size_t)b->db.n_reads);                                                               \
+		c->rt.d2h(intv4, b->work.intv, sizeof(arx::Biv) * (size_t)b->db.n_reads * arx::CAP_INTV);                                   \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_debug_chains(arx_ctx *h, arx_batch *bh, int32_t *occ_off, int32_t *n_chain, arx_chain *chains, arx_seed *seeds)   \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.cout) return ARX_E_ARG;                                                                                        \
+		static_assert(sizeof(arx_chain) == sizeof(arx::Chain) && sizeof(arx_seed) == sizeof(arx::Seed), "C-ABI structs must mirror the device structs"); \
+		c->rt.d2h(occ_off, b->work.occ_off, 4 * ((size_t)b->db.n_reads + 1));                                                       \
+		c->rt.d2h(n_chain, b->work.n_chain, 4 * (size_t)b->db.n_reads);                                                             \
+		c->rt.d2h(chains, b->work.cout, sizeof(arx::Chain) * (size_t)b->work.T);                                                    \
+		c->rt.d2h(seeds, b->work.sout, sizeof(arx::Seed) * (size_t)b->work.T);                                                      \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_debug_core(arx_ctx *h, arx_batch *bh, int32_t *n_core, arx_reg *regs)                                             \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.n_core) return ARX_E_ARG;                                                                                      \
+		c->rt.d2h(n_core, b->work.n_core, 4 * (size_t)b->db.n_reads);                                                               \
+		c->rt.d2h(regs, b->work.regs, sizeof(arx::Reg) * (size_t)b->work.T);                                                        \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	void arx_batch_free(arx_ctx *, arx_batch *bh) { delete (Bat *)bh; }                                                             \
+	int arx_kernel_times(arx_ctx *h, int32_t cap, char *names, int32_t name_w, double *ms, int64_t *calls, int64_t *items)          \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		int n = 0;                                                                                                                  \
+		for (auto &kv : c->rt.timers()) {                                                                                           \
+			if (n >= cap) break;                                                                                                    \
+			snprintf(names + (size_t)n * name_w, name_w, "%s", kv.first.c_str());                                                   \
+			ms[n] = kv.second.ms; calls[n] = kv.second.calls; items[n] = kv.second.items; ++n;                                      \
+		}                                                                                                                           \
+		return n;                                                                                                                   \
+	}                                                                                                                               \
+	void arx_kernel_times_reset(arx_ctx *h, int32_t enable) { ((Ctx *)h)->rt.timers_reset(enable != 0); }                           \
+	}

@@ -1,0 +1,253 @@
+// dev_chain.h -- seed chaining and chain filtering, one read per thread.
+// Agrees with mem_chain / test_and_merge / mem_chain_weight / mem_chain_flt (bwamem.c:190-385) including the
+// B-tree lookup semantics of kbtree.h (which duplicate key is found depends on the tree shape) and the unstable
+// introsort used to rank chains by weight.
+#pragma once
+#include "arx_dev.h"
+
+namespace arx {
+
+// B-tree of minimum degree t = 5: KB_DEFAULT_SIZE 512 with a 40-byte key gives t = ((512-4-8)/(8+40)+1)>>1 (kbtree.h:56,388)
+constexpr int BT_T = 5, BT_MAXK = 2 * BT_T - 1;
+struct BtNode { int32_t is_internal, n; int32_t key[BT_MAXK]; int32_t child[BT_MAXK + 1]; };
+
+struct BTree {
+	BtNode *nodes;      // per-read slice of the node pool
+	const Chain *ch;    // per-read slice of the chain pool (keys are chain indices ordered by Chain::pos)
+	int n_nodes, cap_nodes, root, n_keys;
+};
+
+ARX_DEVI int bt_new(BTree &b)
+{
+	if (b.n_nodes >= b.cap_nodes) return -1;
+	BtNode &x = b.nodes[b.n_nodes];
+	x.is_internal = 0; x.n = 0;
+	return b.n_nodes++;
+}
+
+// __kb_getp_aux (kbtree.h:117-131): first key >= pos inside one node; *r = sign(pos - key[result])
+ARX_DEVI int bt_getp_aux(const BTree &b, int xi, int64_t pos, int *r)
+{
+	const BtNode &x = b.nodes[xi];
+	int begin = 0, end = x.n;
+	if (x.n == 0) return -1;
+	while (begin < end) {
+		int mid = (begin + end) >> 1;
+		if (b.ch[x.key[mid]].pos < pos) begin = mid + 1; else end = mid;
+	}
+	if (begin == x.n) { *r = 1; return x.n - 1; }
+	int64_t kp = b.ch[x.key[begin]].pos;
+	*r = (pos > kp) - (pos < kp);
+	if (*r < 0) --begin;
+	return begin;
+}
+
+// kb_intervalp (kbtree.h:151-168), `lower` only -- mem_chain ignores `upper` (bwamem.c:289-290)
+ARX_DEVI int bt_lower(const BTree &b, int64_t pos)
+{
+	int xi = b.root, lower = -1, r = 0;
+	for (;;) {
+		const BtNode &x = b.nodes[xi];
+		int i = bt_getp_aux(b, xi, pos, &r);
+		if (i >= 0 && r == 0) return x.key[i];
+		if (i >= 0) lower = x.key[i];
+		if (!x.is_internal) return lower;
+		xi = x.child[i + 1];
+	}
+}
+
+ARX_DEVI bool bt_split(BTree &b, int xi, int i, int yi) // __kb_split (kbtree.h:177-192)
+{
+	int zi = bt_new(b);
+	if (zi < 0) return false;
+	BtNode &x = b.nodes[xi], &y = b.nodes[yi], &z = b.nodes[zi];
+	z.is_internal = y.is_internal;
+	z.n = BT_T - 1;
+	for (int j = 0; j < BT_T - 1; ++j) z.key[j] = y.key[BT_T + j];
+	if (y.is_internal) for (int j = 0; j < BT_T; ++j) z.child[j] = y.child[BT_T + j];
+	y.n = BT_T - 1;
+	for (int j = x.n; j > i; --j) x.child[j + 1] = x.child[j];
+	x.child[i + 1] = zi;
+	for (int j = x.n - 1; j >= i; --j) x.key[j + 1] = x.key[j];
+	x.key[i] = y.key[BT_T - 1];
+	++x.n;
+	return true;
+}
+
+ARX_DEV bool bt_put(BTree &b, int ci) // kb_putp + __kb_putp_aux (kbtree.h:193-226)
+{
+	int64_t pos = b.ch[ci].pos;
+	int r;
+	++b.n_keys;
+	if (b.nodes[b.root].n == BT_MAXK) {
+		int si = bt_new(b), old = b.root;
+		if (si < 0) return false;
+		b.root = si; b.nodes[si].is_internal = 1; b.nodes[si].n = 0; b.nodes[si].child[0] = old;
+		if (!bt_split(b, si, 0, old)) return false;
+	}
+	int xi = b.root;
+	for (;;) {
+		BtNode &x = b.nodes[xi];
+		if (!x.is_internal) {
+			int i = bt_getp_aux(b, xi, pos, &r);
+			for (int j = x.n - 1; j > i; --j) x.key[j + 1] = x.key[j];
+			x.key[i + 1] = ci;
+			++x.n;
+			return true;
+		}
+		int i = bt_getp_aux(b, xi, pos, &r) + 1;
+		if (b.nodes[x.child[i]].n == BT_MAXK) {
+			if (!bt_split(b, xi, i, x.child[i])) return false;
+			if (pos > b.ch[x.key[i]].pos) ++i;
+		}
+		xi = x.child[i];
+	}
+}
+
+// in-order traversal (kbtree.h:352-375) with an explicit stack; the tree height is tiny (<= 8 for 10^5 keys)
+ARX_DEV int bt_traverse(const BTree &b, int *out)
+{
+	int st_x[16], st_i[16], st_p[16], top = 0, n = 0;
+	st_x[0] = b.root; st_i[0] = 0; st_p[0] = 0;
+	while (top >= 0) {
+		const BtNode &x = b.nodes[st_x[top]];
+		int i = st_i[top];
+		if (st_p[top] == 0) { // first descend into child i
+			st_p[top] = 1;
+			if (x.is_internal) { ++top; st_x[top] = x.child[i]; st_i[top] = 0; st_p[top] = 0; continue; }
+		}
+		if (i < x.n) { out[n++] = x.key[i]; st_i[top] = i + 1; st_p[top] = 0; } // then emit key i
+		else --top;
+	}
+	return n;
+}
+
+// test_and_merge (bwamem.c:190-211) on a chain whose seeds form a linked list (head = seeds[0], tail = last)
+ARX_DEVI int test_and_merge(int64_t l_pac, Chain &c, const Seed *occ, int *next, int g, int seed_rid)
+{
+	const Seed p = occ[g], first = occ[c.head], last = occ[c.tail];
+	int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
+	if (seed_rid != c.rid) return 0;
+	if (p.qbeg >= first.qbeg && p.qbeg + p.len <= qend && p.rbeg >= first.rbeg && p.rbeg + p.len <= rend) return 1; // contained
+	if ((last.rbeg < l_pac || first.rbeg < l_pac) && p.rbeg >= l_pac) return 0; // different strand
+	int64_t x = p.qbeg - last.qbeg, y = p.rbeg - last.rbeg;
+	if (y >= 0 && x - y <= OPT_W && y - x <= OPT_W && x - last.len < OPT_MAX_CHAIN_GAP && y - last.len < OPT_MAX_CHAIN_GAP) {
+		next[c.tail] = g; next[g] = -1; c.tail = g; ++c.n;
+		return 1;
+	}
+	return 0;
+}
+
+ARX_DEV int chain_weight(const Chain &c, const Seed *occ, const int *next) // mem_chain_weight (bwamem.c:213-234)
+{
+	int64_t end = 0;
+	int w = 0, tmp;
+	for (int g = c.head; g >= 0; g = next[g]) {
+		const Seed s = occ[g];
+		if (s.qbeg >= end) w += s.len;
+		else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+		end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+	}
+	tmp = w; w = 0; end = 0;
+	for (int g = c.head; g >= 0; g = next[g]) {
+		const Seed s = occ[g];
+		if (s.rbeg >= end) w += s.len;
+		else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+		end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+	}
+	w = w < tmp ? w : tmp;
+	return w < 1 << 30 ? w : (1 << 30) - 1;
+}
+
+struct WeightGt { const Chain *c; ARX_DEVI bool operator()(int a, int b) const { return c[a].w > c[b].w; } };
+
+// One read: occurrences [g0, g1) (already located, in interval order) -> filtered chains + their seeds, compacted.
+// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 2*(g1-g0) ints, nodes cap_nodes entries.
+// Returns the number of chains kept (mem_chain + mem_chain_flt), or -1 on pool exhaustion.
+ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int n_intv, const Seed *occ, int n_occ,
+                             int *next, Chain *ctmp, BtNode *nodes, int cap_nodes, int *iscr, Chain *cout, Seed *sout, int sout_base)
+{
+	if (len < OPT_MIN_SEED_LEN || n_occ == 0) return 0;
+	// frac_rep: share of the query covered by seeds occurring more than max_occ times (bwamem.c:265-272)
+	int b = 0, e = 0, l_rep = 0;
+	for (int i = 0; i < n_intv; ++i) {
+		int sb = (int)(intv[i].info >> 32), se = (int)(uint32_t)intv[i].info;
+		if (intv[i].s <= (uint64_t)OPT_MAX_OCC) continue;
+		if (sb > e) { l_rep += e - b; b = sb; e = se; }
+		else e = e > se ? e : se;
+	}
+	l_rep += e - b;
+	float frac_rep = (float)l_rep / len;
+	BTree bt;
+	bt.nodes = nodes; bt.ch = ctmp; bt.n_nodes = 0; bt.cap_nodes = cap_nodes; bt.n_keys = 0;
+	bt.root = bt_new(bt);
+	int n_ch = 0;
+	for (int g = 0; g < n_occ; ++g) {
+		const Seed s = occ[g];
+		int rid = intv2rid(ix, s.rbeg, s.rbeg + s.len);
+		if (rid < 0) continue; // spans contigs or the strand boundary
+		bool to_add = true;
+		if (bt.n_keys) {
+			int lower = bt_lower(bt, s.rbeg);
+			if (lower >= 0 && test_and_merge(ix.l_pac, ctmp[lower], occ, next, g, rid)) to_add = false;
+		}
+		if (to_add) {
+			Chain &c = ctmp[n_ch];
+			c.pos = s.rbeg; c.rid = rid; c.n = 1; c.head = c.tail = g; next[g] = -1;
+			c.is_alt = ix.ann_alt[rid] ? 1 : 0;
+			c.w = 0; c.kept = 0; c.first = -1; c.seed_off = 0; c.frac_rep = frac_rep;
+			if (!bt_put(bt, n_ch)) return -1;
+			++n_ch;
+		}
+	}
+	if (n_ch == 0) return 0;
+	int *ord = iscr, *kept_idx = iscr + n_occ;
+	int n = bt_traverse(bt, ord); // chains in key order = the array mem_chain returns
+	// mem_chain_flt (bwamem.c:327-385)
+	for (int i = 0; i < n; ++i) { Chain &c = ctmp[ord[i]]; c.first = -1; c.kept = 0; c.w = chain_weight(c, occ, next); }
+	WeightGt gt; gt.c = ctmp;
+	ks_introsort(n, ord, gt);
+	int n_kept = 0;
+	ctmp[ord[0]].kept = 3;
+	kept_idx[n_kept++] = 0;
+#define CHN_BEG(c) (occ[(c).head].qbeg)
+#define CHN_END(c) (occ[(c).tail].qbeg + occ[(c).tail].len)
+	for (int i = 1; i < n; ++i) {
+		Chain &ci = ctmp[ord[i]];
+		int large_ovlp = 0, k;
+		for (k = 0; k < n_kept; ++k) {
+			Chain &cj = ctmp[ord[kept_idx[k]]];
+			int b_max = CHN_BEG(cj) > CHN_BEG(ci) ? CHN_BEG(cj) : CHN_BEG(ci);
+			int e_min = CHN_END(cj) < CHN_END(ci) ? CHN_END(cj) : CHN_END(ci);
+			if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
+				int li = CHN_END(ci) - CHN_BEG(ci), lj = CHN_END(cj) - CHN_BEG(cj);
+				int min_l = li < lj ? li : lj;
+				if ((float)(e_min - b_max) >= min_l * OPT_MASK_LEVEL && min_l < OPT_MAX_CHAIN_GAP) {
+					large_ovlp = 1;
+					if (cj.first < 0) cj.first = i;
+					if ((float)ci.w < cj.w * OPT_DROP_RATIO && cj.w - ci.w >= OPT_MIN_SEED_LEN << 1) break;
+				}
+			}
+		}
+		if (k == n_kept) { kept_idx[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
+	}
+#undef CHN_BEG
+#undef CHN_END
+	for (int i = 0; i < n_kept; ++i) {
+		const Chain &c = ctmp[ord[kept_idx[i]]];
+		if (c.first >= 0) ctmp[ord[c.first]].kept = 1;
+	}
+	// max_chain_extend = 1<<30 never triggers (bwamem.c:373-378); compact the survivors with their seeds in list order
+	int m = 0, so = 0;
+	for (int i = 0; i < n; ++i) {
+		const Chain &c = ctmp[ord[i]];
+		if (c.kept == 0) continue;
+		Chain o = c;
+		o.seed_off = sout_base + so;
+		for (int g = c.head; g >= 0; g = next[g]) sout[so++] = occ[g];
+		cout[m++] = o;
+	}
+	return m;
+}
+
+} // namespace arx

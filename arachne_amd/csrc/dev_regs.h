@@ -1,0 +1,424 @@
+// dev_regs.h -- alignment regions: the per-read extension state machine (mem_chain2aln), region de-duplication
+// (mem_sort_dedup_patch / mem_patch_reg), the per-pair mate-rescue state machine (GoBwaMemMateSW driving mem_matesw)
+// and region -> alignment record (mem_reg2aln).
+//
+// The reference extends seeds one after another because each decision looks at the regions found so far.  Here every
+// read (pair) is a small state machine: a "step" kernel advances it to its next dynamic-programming task, a dense task
+// kernel runs all pending tasks of the batch, and the next step consumes the results.
+#pragma once
+#include "arx_dev.h"
+#include "dev_sw.h"
+
+namespace arx {
+
+// ------------------------------------------------------------------------------------------------
+// mem_chain2aln (bwamem.c:632-786) as a state machine
+// ------------------------------------------------------------------------------------------------
+enum { PH_PICK = 0, PH_LEFT = 1, PH_RIGHT = 2, PH_DONE = 3 };
+
+struct ExtState {
+	int64_t rmax0, rmax1;
+	Reg a;                 // region being built
+	int32_t ci, k, phase, band_try, n_regs, seed, sc0, aw0, aw1, prev, rstart, pad;  // initial state: ci = -1, k = -1, phase = PH_PICK
+};
+
+struct SeedKeyLt { // ascending (score<<32 | index) with score == len (bwamem.c:663-665); keys are unique
+	const Seed *s;
+	ARX_DEVI bool operator()(int a, int b) const { return s[a].len < s[b].len || (s[a].len == s[b].len && a < b); }
+};
+
+// set up the chain: reference window (bwamem.c:642-660) and the seed visiting order
+ARX_DEV void ext_begin_chain(const IndexView &ix, int l_query, const Chain &c, const Seed *seeds, int *srt, ExtState &st)
+{
+	int64_t l_pac = ix.l_pac, r0 = l_pac << 1, r1 = 0;
+	for (int i = 0; i < c.n; ++i) {
+		const Seed t = seeds[i];
+		int64_t b = t.rbeg - (t.qbeg + cal_max_gap(t.qbeg));
+		int64_t e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + cal_max_gap(l_query - t.qbeg - t.len));
+		r0 = r0 < b ? r0 : b;
+		r1 = r1 > e ? r1 : e;
+	}
+	r0 = r0 > 0 ? r0 : 0;
+	r1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
+	if (r0 < l_pac && l_pac < r1) {
+		if (seeds[0].rbeg < l_pac) r1 = l_pac; else r0 = l_pac;
+	}
+	int rid;
+	fetch_clamp(ix, &r0, seeds[0].rbeg, &r1, &rid);
+	st.rmax0 = r0; st.rmax1 = r1;
+	for (int i = 0; i < c.n; ++i) srt[i] = i;
+	SeedKeyLt lt; lt.s = seeds;
+	ks_introsort(c.n, srt, lt);
+	st.k = c.n - 1;
+}
+
+// Is seed s (srt position k) already explained by an earlier region of this read?  (bwamem.c:671-706)
+ARX_DEV bool ext_seed_skipped(int l_query, const Chain &c, const Seed *seeds, const int *srt, int k, const Reg *av, int n_av)
+{
+	const Seed s = seeds[srt[k]];
+	int i;
+	for (i = 0; i < n_av; ++i) {
+		const Reg &p = av[i];
+		int64_t rd;
+		int qd, w, max_gap;
+		if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
+		if (s.len - p.seedlen0 > .1 * l_query) continue;
+		qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+		max_gap = cal_max_gap(qd < rd ? qd : (int)rd);
+		w = max_gap < p.w ? max_gap : p.w;
+		if (qd - rd < w && rd - qd < w) break;
+		qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+		max_gap = cal_max_gap(qd < rd ? qd : (int)rd);
+		w = max_gap < p.w ? max_gap : p.w;
+		if (qd - rd < w && rd - qd < w) break;
+	}
+	if (i == n_av) return false;
+	for (i = k + 1; i < c.n; ++i) { // an extended, overlapping, off-diagonal seed keeps this one alive
+		if (srt[i] < 0) continue;
+		const Seed t = seeds[srt[i]];
+		if (t.len < s.len * .95) continue;
+		if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+		if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+	}
+	return i == c.n;
+}
+
+ARX_DEVI void ext_make_task(ExtTask &t, int owner, int read_base, int l_query, const Seed &s, const ExtState &st, bool left)
+{
+	t.owner = owner;
+	if (left) {
+		t.qoff = read_base + s.qbeg - 1; t.qdir = -1; t.qlen = s.qbeg;
+		t.tpos = s.rbeg - 1; t.tdir = -1; t.tlen = (int)(s.rbeg - st.rmax0);
+		t.w = OPT_W << st.band_try; t.h0 = s.len * OPT_A;
+	} else {
+		int qe = s.qbeg + s.len;
+		t.qoff = read_base + qe; t.qdir = 1; t.qlen = l_query - qe;
+		t.tpos = s.rbeg + s.len; t.tdir = 1; t.tlen = (int)(st.rmax1 - (s.rbeg + s.len));
+		t.w = OPT_W << st.band_try; t.h0 = st.sc0;
+	}
+}
+
+// Advance one read until it needs a DP (returns true, task filled) or has no seed left (returns false).
+// chains/seeds/srt/av are this read's slices; res is the result of the task emitted by the previous call.
+ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query, const Chain *chains, int n_chains,
+                      const Seed *seed_pool, int *srt_pool, Reg *av, ExtState &st, const ExtRes &res, ExtTask &task)
+{
+	for (;;) {
+		if (st.phase == PH_DONE) return false;
+		const Chain *c = (st.ci >= 0 && st.ci < n_chains) ? &chains[st.ci] : 0;
+		const Seed *seeds = c ? seed_pool + c->seed_off : 0;
+		int *srt = c ? srt_pool + c->seed_off : 0;
+		if (st.phase == PH_LEFT) {
+			const Seed s = seeds[st.seed];
+			Reg &a = st.a;
+			a.score = res.score;
+			st.aw0 = OPT_W << st.band_try;
+			if (!(a.score == st.prev || res.max_off < (st.aw0 >> 1) + (st.aw0 >> 2)) && st.band_try + 1 < OPT_MAX_BAND_TRY) {
+				st.prev = a.score; ++st.band_try;
+				ext_make_task(task, owner, read_base, l_query, s, st, true);
+				return true;
+			}
+			if (res.gscore <= 0 || res.gscore <= a.score - OPT_PEN_CLIP5) { a.qb = s.qbeg - res.qle; a.rb = s.rbeg - res.tle; a.truesc = a.score; }
+			else { a.qb = 0; a.rb = s.rbeg - res.gtle; a.truesc = res.gscore; }
+			st.phase = PH_RIGHT; st.rstart = 0;
+		}
+		if (st.phase == PH_RIGHT) {
+			const Seed s = seeds[st.seed];
+			Reg &a = st.a;
+			bool finish = false;
+			if (!st.rstart) {
+				if (s.qbeg + s.len != l_query) {
+					st.sc0 = a.score; st.prev = a.score; st.band_try = 0; st.rstart = 1;
+					ext_make_task(task, owner, read_base, l_query, s, st, false);
+					return true;
+				}
+				a.qe = l_query; a.re = s.rbeg + s.len;
+				finish = true;
+			} else {
+				a.score = res.score;
+				st.aw1 = OPT_W << st.band_try;
+				if (!(a.score == st.prev || res.max_off < (st.aw1 >> 1) + (st.aw1 >> 2)) && st.band_try + 1 < OPT_MAX_BAND_TRY) {
+					st.prev = a.score; ++st.band_try;
+					ext_make_task(task, owner, read_base, l_query, s, st, false);
+					return true;
+				}
+				int qe = s.qbeg + s.len;
+				if (res.gscore <= 0 || res.gscore <= a.score - OPT_PEN_CLIP3) { a.qe = qe + res.qle; a.re = s.rbeg + s.len + res.tle; a.truesc += a.score - st.sc0; }
+				else { a.qe = l_query; a.re = s.rbeg + s.len + res.gtle; a.truesc += res.gscore - st.sc0; }
+				finish = true;
+			}
+			if (finish) {
+				a.seedcov = 0;
+				for (int i = 0; i < c->n; ++i) {
+					const Seed t = seeds[i];
+					if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) a.seedcov += t.len;
+				}
+				a.w = st.aw0 > st.aw1 ? st.aw0 : st.aw1;
+				a.seedlen0 = s.len;
+				a.frac_rep = c->frac_rep;
+				av[st.n_regs++] = a;
+				--st.k;
+				st.phase = PH_PICK;
+			}
+		}
+		// PH_PICK
+		if (st.k < 0) { // next chain
+			++st.ci;
+			if (st.ci >= n_chains) { st.phase = PH_DONE; return false; }
+			c = &chains[st.ci]; seeds = seed_pool + c->seed_off; srt = srt_pool + c->seed_off;
+			if (c->n == 0) { st.k = -1; continue; }
+			ext_begin_chain(ix, l_query, *c, seeds, srt, st);
+		}
+		if (ext_seed_skipped(l_query, *c, seeds, srt, st.k, av, st.n_regs)) { srt[st.k] = -1; --st.k; continue; }
+		{
+			st.seed = srt[st.k];
+			const Seed s = seeds[st.seed];
+			Reg &a = st.a;
+			a = Reg();
+			a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.alt_sc = a.csub = a.sub_n = a.seedcov = a.secondary = a.secondary_all = a.n_comp = a.is_alt = 0; a.pad = 0;
+			a.w = st.aw0 = st.aw1 = OPT_W;
+			a.score = a.truesc = -1;
+			a.rid = c->rid;
+			a.seedlen0 = 0; a.frac_rep = 0.f;
+			if (s.qbeg) {
+				st.phase = PH_LEFT; st.band_try = 0; st.prev = -1;
+				ext_make_task(task, owner, read_base, l_query, s, st, true);
+				return true;
+			}
+			a.score = a.truesc = s.len * OPT_A; a.qb = 0; a.rb = s.rbeg;
+			st.phase = PH_RIGHT; st.rstart = 0;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// mem_sort_dedup_patch (bwamem.c:437-489) + mem_patch_reg (bwamem.c:406-435)
+// ------------------------------------------------------------------------------------------------
+struct RegReLt { const Reg *r; ARX_DEVI bool operator()(int a, int b) const { return r[a].re < r[b].re; } };
+struct RegScoreLt {
+	const Reg *r;
+	ARX_DEVI bool operator()(int x, int y) const
+	{
+		const Reg &a = r[x], &b = r[y];
+		return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb)));
+	}
+};
+
+template <class LT> ARX_DEV void permute_regs(int n, Reg *a, Reg *tmp, int *idx, LT lt)
+{
+	for (int i = 0; i < n; ++i) idx[i] = i;
+	ks_introsort(n, idx, lt);
+	for (int i = 0; i < n; ++i) tmp[i] = a[idx[i]];
+	for (int i = 0; i < n; ++i) a[i] = tmp[i];
+}
+
+// query == nullptr disables patching (the mate-rescue call site passes bns = pac = query = 0, bwamem_pair.c:175)
+ARX_DEV int patch_reg(const IndexView &ix, const uint8_t *query, const Reg &a, const Reg &b, int32_t *eh, int *w_)
+{
+	if (query == 0) return 0;
+	if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
+	if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+	int w = (int)((a.re - b.rb) - (a.qe - b.qb));
+	w = w > 0 ? w : -w;
+	double r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);
+	r = r > 0. ? r : -r;
+	if (a.re < b.rb || a.qe < b.qb) { if (w > OPT_W << 1 || r >= (double)0.05f) return 0; }
+	else if (w > OPT_W << 2 || r >= (double)(0.05f * 2)) return 0;
+	w += a.w + b.w;
+	w = w < OPT_W << 2 ? w : OPT_W << 2;
+	int score = 0, nc, nm;
+	gen_cigar2(ix, w, query, a.qb, b.qe, a.rb, b.re, eh, 0, false, 0, 0, &score, &nc, &nm);
+	int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
+	int r_s = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
+	if ((double)score / (q_s > r_s ? q_s : r_s) < (double)0.90f) return 0;
+	*w_ = w;
+	return score;
+}
+
+ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, Reg *a, Reg *tmp, int *idx, int32_t *eh)
+{
+	int m, i, j;
+	if (n <= 1) return n;
+	RegReLt lt1; lt1.r = a;
+	permute_regs(n, a, tmp, idx, lt1);
+	for (i = 0; i < n; ++i) a[i].n_comp = 1;
+	for (i = 1; i < n; ++i) {
+		Reg &p = a[i];
+		if (p.rid != a[i - 1].rid || p.rb >= a[i - 1].re + OPT_MAX_CHAIN_GAP) continue;
+		for (j = i - 1; j >= 0 && p.rid == a[j].rid && p.rb < a[j].re + OPT_MAX_CHAIN_GAP; --j) {
+			Reg &q = a[j];
+			int64_t orr, oq, mr, mq;
+			int score, w;
+			if (q.qe == q.qb) continue;
+			orr = q.re - p.rb;
+			oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+			mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+			mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+			if ((float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq) {
+				if (p.score < q.score) { p.qe = p.qb; break; }
+				else q.qe = q.qb;
+			} else if (q.rb < p.rb && (score = patch_reg(ix, query, q, p, eh, &w)) > 0) {
+				p.n_comp += q.n_comp + 1;
+				p.seedcov = p.seedcov > q.seedcov ? p.seedcov : q.seedcov;
+				p.sub = p.sub > q.sub ? p.sub : q.sub;
+				p.csub = p.csub > q.csub ? p.csub : q.csub;
+				p.qb = q.qb; p.rb = q.rb;
+				p.truesc = p.score = score;
+				p.w = w;
+				q.qb = q.qe;
+			}
+		}
+	}
+	for (i = 0, m = 0; i < n; ++i)
+		if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+	n = m;
+	RegScoreLt lt2; lt2.r = a;
+	permute_regs(n, a, tmp, idx, lt2);
+	for (i = 1; i < n; ++i)
+		if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb) a[i].qe = a[i].qb;
+	for (i = 1, m = 1; i < n; ++i)
+		if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+	return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mate rescue: GoBwaMemMateSW's two loops (/root/reference/src/gobwa/gobwa.go:285-324) around mem_matesw
+// (bwamem_pair.c:111-180) with the fixed insert model (only FR valid, [-35, 500]).
+// ------------------------------------------------------------------------------------------------
+struct ResState {
+	int64_t rb, re;        // clamped window of the pending SW
+	int32_t e, i, num, n_snap, best[2], phase, pad;
+};
+struct SwTask { int64_t rb, re; int32_t pair, o; };
+
+ARX_DEVI int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) // mem_infer_dir (bwamem_pair.c:23-31)
+{
+	int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+	int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+// Insert the rescued region and re-sort (bwamem_pair.c:150-176).  ma has room for one more entry.
+ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Res &aln, int64_t rb, Reg *ma, int n_ma, Reg *tmp, int *idx)
+{
+	const int64_t l_pac = ix.l_pac;
+	if (aln.score >= OPT_MIN_SEED_LEN && aln.qb >= 0) { // is_rev == 1 for the FR orientation
+		Reg b = Reg();
+		b.rb = b.re = 0; b.truesc = b.sub = b.alt_sc = b.sub_n = b.w = b.secondary_all = b.seedlen0 = b.n_comp = 0; b.frac_rep = 0.f; b.pad = 0;
+		b.rid = a.rid;
+		b.is_alt = a.is_alt;
+		b.qb = l_ms - (aln.qe + 1);
+		b.qe = l_ms - aln.qb;
+		b.rb = (l_pac << 1) - (rb + aln.te + 1);
+		b.re = (l_pac << 1) - (rb + aln.tb);
+		b.score = aln.score;
+		b.csub = aln.score2;
+		b.secondary = -1;
+		b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+		int i, at;
+		++n_ma;
+		for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
+		at = i;
+		for (i = n_ma - 1; i > at; --i) ma[i] = ma[i - 1];
+		ma[at] = b;
+	}
+	return sort_dedup_patch(ix, 0, n_ma, ma, tmp, idx, 0);
+}
+
+// Advance one pair until it needs a SW (true) or both rescue loops are finished (false).
+// regs[e]/n_regs[e]: the two reads' region lists (with spare capacity).
+ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *const regs[2], int *n_regs[2], Reg *const tmp[2], int *const idx[2],
+                         ResState &st, const U8Res &res, SwTask &task)
+{
+	for (;;) {
+		if (st.phase == 2) return false;
+		const int e = st.e, o = 1 - e;
+		if (st.phase == 1) { // a SW came back: ma = the other read's list
+			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], res, st.rb, regs[o], *n_regs[o], tmp[o], idx[o]);
+			st.phase = 0; ++st.i;
+		}
+		if (st.i >= st.n_snap || st.num >= MAX_RESCUE || lens2[o] <= 0) {
+			if (e == 1) { st.e = 0; st.i = 0; st.num = 0; st.n_snap = *n_regs[0]; continue; } // second loop walks the POST-rescue read-1 list
+			st.phase = 2;
+			return false;
+		}
+		const Reg a = regs[e][st.i];
+		if (a.score < st.best[e] - 25) { ++st.i; continue; } // threshold stays the PRE-rescue best (gobwa.go:302-312)
+		++st.num;
+		bool skip = false; // an existing mate region already sits in the FR window (bwamem_pair.c:118-124)
+		for (int j = 0; j < *n_regs[o]; ++j) {
+			int64_t dist;
+			int r = infer_dir(ix.l_pac, a.rb, regs[o][j].rb, &dist);
+			if (r == 1 && dist >= PES_LOW && dist <= PES_HIGH) { skip = true; break; }
+		}
+		if (skip) { ++st.i; continue; }
+		const int l_ms = lens2[o];
+		int64_t rb = a.rb + PES_LOW - l_ms, re = a.rb + PES_HIGH; // r = 1: mate reversed, larger coordinate
+		int rid = -1;
+		if (rb < 0) rb = 0;
+		if (re > ix.l_pac << 1) re = ix.l_pac << 1;
+		if (rb < re) fetch_clamp(ix, &rb, (rb + re) >> 1, &re, &rid);
+		if (a.rid == rid && re - rb >= OPT_MIN_SEED_LEN) {
+			st.rb = rb; st.re = re; st.phase = 1;
+			task.rb = rb; task.re = re; task.pair = pair; task.o = o;
+			return true;
+		}
+		++st.i; // nothing aligned: ma stays as it is
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// mem_reg2aln (bwamem.c:1086-1156); mapq is not produced (Arachne never reads it)
+// ------------------------------------------------------------------------------------------------
+ARX_DEVI int infer_bw(int l1, int l2, int score, int a, int q, int r) // bwamem.c:792-799 with r == 1
+{
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	int w = (l1 < l2 ? l1 : l2) * a - score - q + 2;
+	if (w < iabs(l1 - l2)) w = iabs(l1 - l2);
+	return w;
+}
+
+// cg: cap words of output CIGAR for this region; returns false when cap is too small (caller retries with a larger slot)
+ARX_DEV bool reg2aln(const IndexView &ix, int l_query, const uint8_t *query, const Reg &ar, int32_t *eh, uint8_t *z, uint32_t *cg, int cap, Aln &a)
+{
+	int i, w2, tmp, NM = -1, score = 0, is_rev, last_sc = -(1 << 30), n_cigar = 0;
+	const int qb = ar.qb, qe = ar.qe;
+	const int64_t rb = ar.rb, re = ar.re;
+	a.flag = ar.secondary >= 0 ? 0x100 : 0;
+	tmp = infer_bw(qe - qb, (int)(re - rb), ar.truesc, OPT_A, OPT_O_DEL, OPT_E_DEL);
+	w2 = infer_bw(qe - qb, (int)(re - rb), ar.truesc, OPT_A, OPT_O_INS, OPT_E_INS);
+	w2 = w2 > tmp ? w2 : tmp;
+	if (w2 > OPT_W) w2 = w2 < ar.w ? w2 : ar.w;
+	i = 0;
+	do {
+		w2 = w2 < OPT_W << 2 ? w2 : OPT_W << 2;
+		gen_cigar2(ix, w2, query, qb, qe, rb, re, eh, z, true, cg + 1, cap - 2, &score, &n_cigar, &NM); // room for both clips
+		if (n_cigar > cap - 2) return false;
+		if (score == last_sc || w2 == OPT_W << 2) break;
+		last_sc = score;
+		w2 <<= 1;
+	} while (++i < 3 && score < ar.truesc - OPT_A);
+	a.NM = NM;
+	int64_t pos = depos(ix, rb < ix.l_pac ? rb : re - 1, &is_rev);
+	a.is_rev = is_rev;
+	uint32_t *c0 = cg + 1;
+	if (n_cigar > 0) { // squeeze out a leading or trailing deletion
+		if ((c0[0] & 0xf) == 2) { pos += c0[0] >> 4; --n_cigar; ++c0; }
+		else if ((c0[n_cigar - 1] & 0xf) == 2) --n_cigar;
+	}
+	if (qb != 0 || qe != l_query) {
+		int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+		if (clip5) { --c0; c0[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
+		if (clip3) c0[n_cigar++] = (uint32_t)clip3 << 4 | 3;
+	}
+	if (c0 != cg) for (i = 0; i < n_cigar; ++i) cg[i] = c0[i]; // c0 >= cg, forward copy is safe
+	a.n_cigar = n_cigar;
+	a.rid = pos2rid(ix, pos);
+	a.pos = pos - ix.ann_off[a.rid];
+	a.score = ar.score; a.sub = ar.sub > ar.csub ? ar.sub : ar.csub;
+	a.is_alt = ar.is_alt; a.alt_sc = ar.alt_sc;
+	return true;
+}
+
+} // namespace arx

@@ -1,0 +1,139 @@
+// hip_rt.h -- the HIP runtime policy of Pipeline<RT>: device memory, kernel launches on one stream, device scan,
+// per-kernel timing with HIP events.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+namespace arx {
+
+#define ARX_HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// generic grid-stride launchers; slot = global thread index (always < max_slots) selects per-thread scratch
+template <class F> __global__ void __launch_bounds__(64) k_items(F f, int n)
+{
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+	for (int i = slot; i < n; i += step) f(i, slot);
+}
+// DP kernels: each thread owns words [threadIdx.x + j*blockDim.x] of the block's LDS, i.e. a [column][lane] layout
+template <class F> __global__ void __launch_bounds__(64) k_rows(F f, int n)
+{
+	extern __shared__ uint32_t lds_rows[];
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+	for (int i = slot; i < n; i += step) f(i, slot, lds_rows + threadIdx.x, (int)blockDim.x);
+}
+
+struct CastI64 { __host__ __device__ int64_t operator()(const int32_t &x) const { return (int64_t)x; } };
+
+struct KernelTimer { double ms = 0; int64_t calls = 0, items = 0; };
+
+struct HipRT {
+	static const char *name() { return "hip:gfx950"; }
+	hipStream_t stream = 0;
+	int n_cu = 256;
+	bool timing = false;
+	std::map<std::string, KernelTimer> tm;
+	hipEvent_t ev0 = 0, ev1 = 0;
+	void *scan_tmp = 0; size_t scan_tmp_bytes = 0; int64_t *d_total = 0;
+
+	std::string init(int device)
+	{
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return "no HIP device visible: libarachne_amd.so needs an MI355X (there is no CPU fallback)";
+		if (device < 0 || device >= n) return "device index out of range";
+		if (hipSetDevice(device) != hipSuccess) return "hipSetDevice failed";
+		hipDeviceProp_t p;
+		if (hipGetDeviceProperties(&p, device) != hipSuccess) return "hipGetDeviceProperties failed";
+		n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+		if (hipStreamCreate(&stream) != hipSuccess) return "hipStreamCreate failed";
+		hipEventCreate(&ev0); hipEventCreate(&ev1);
+		hipMalloc(&d_total, 8);
+		return "";
+	}
+	~HipRT()
+	{
+		if (scan_tmp) hipFree(scan_tmp);
+		if (d_total) hipFree(d_total);
+		if (ev0) hipEventDestroy(ev0);
+		if (ev1) hipEventDestroy(ev1);
+		if (stream) hipStreamDestroy(stream);
+	}
+	template <class T> T *alloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; }
+	void free(void *p) { if (p) hipFree(p); }
+	void h2d(void *d, const void *s, size_t bytes) { if (bytes) { ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream)); ARX_HIP_CHECK(hipStreamSynchronize(stream)); } }
+	void d2h(void *d, const void *s, size_t bytes) { if (bytes) { ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); ARX_HIP_CHECK(hipStreamSynchronize(stream)); } }
+	void memset0(void *d, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, 0, bytes, stream)); }
+	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+	// 8 resident 64-thread blocks per CU give every SIMD two waves of these latency-bound kernels
+	int max_blocks() const { return n_cu * 8; }
+	int max_slots() const { return max_blocks() * 64; }
+	int max_slots_small() const { return n_cu * 64; }
+
+	struct Scope {
+		HipRT &rt; const char *nm; int64_t items;
+		Scope(HipRT &r, const char *n, int64_t it) : rt(r), nm(n), items(it) { if (rt.timing) hipEventRecord(rt.ev0, rt.stream); }
+		~Scope()
+		{
+			if (!rt.timing) return;
+			hipEventRecord(rt.ev1, rt.stream); hipEventSynchronize(rt.ev1);
+			float ms = 0; hipEventElapsedTime(&ms, rt.ev0, rt.ev1);
+			KernelTimer &t = rt.tm[nm]; t.ms += ms; ++t.calls; t.items += items;
+		}
+	};
+	std::map<std::string, KernelTimer> &timers() { return tm; }
+	void timers_reset(bool enable) { tm.clear(); timing = enable; }
+
+	template <class F> void launch(const char *nm, int n, const F &f)
+	{
+		if (n <= 0) return;
+		Scope sc(*this, nm, n);
+		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
+		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	template <class F> void launch_small(const char *nm, int n, const F &f)
+	{
+		if (n <= 0) return;
+		Scope sc(*this, nm, n);
+		int blocks = (n + 63) / 64; if (blocks > n_cu) blocks = n_cu;
+		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	template <class F> void launch_rows(const char *nm, int n, const F &f, int words_per_thread)
+	{
+		if (n <= 0) return;
+		Scope sc(*this, nm, n);
+		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
+		size_t lds = (size_t)words_per_thread * 64 * 4;
+		hipLaunchKernelGGL(k_rows<F>, dim3(blocks), dim3(64), lds, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	// out[0..n] = exclusive prefix sums of in[0..n); returns the total as int64
+	int64_t exclusive_scan(const int32_t *in, int32_t *out, int n)
+	{
+		Scope sc(*this, "scan", n);
+		size_t need = 0;
+		hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, n, stream);
+		size_t need2 = 0;
+		hipcub::TransformInputIterator<int64_t, CastI64, const int32_t *> it(in, CastI64());
+		hipcub::DeviceReduce::Sum(nullptr, need2, it, d_total, n, stream);
+		if (need2 > need) need = need2;
+		if (need > scan_tmp_bytes) { if (scan_tmp) hipFree(scan_tmp); ARX_HIP_CHECK(hipMalloc(&scan_tmp, need)); scan_tmp_bytes = need; }
+		size_t nb = scan_tmp_bytes;
+		ARX_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, nb, in, out, n, stream));
+		nb = scan_tmp_bytes;
+		ARX_HIP_CHECK(hipcub::DeviceReduce::Sum(scan_tmp, nb, it, d_total, n, stream));
+		int64_t total = 0;
+		d2h(&total, d_total, 8);
+		int32_t t32 = (int32_t)(total < ((int64_t)1 << 31) ? total : 0x7fffffff);
+		ARX_HIP_CHECK(hipMemcpyAsync(out + n, &t32, 4, hipMemcpyHostToDevice, stream));
+		ARX_HIP_CHECK(hipStreamSynchronize(stream));
+		return total;
+	}
+};
+
+} // namespace arx

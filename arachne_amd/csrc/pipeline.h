@@ -1,0 +1,401 @@
+// pipeline.h -- host orchestration of one batch through the device path, written once against a small runtime
+// policy RT (device memory, launches, scan).  The product instantiates it with HipRT (hip_rt.h): every stage below
+// runs as a HIP kernel on the MI355X.
+//
+// Stage order = call order of the reference for one pair (/root/reference/src/gobwa/gobwa.go:226-337,400-415):
+//   seed (mem_collect_intv) -> locate (bwt_sa) -> chain+filter (mem_chain, mem_chain_flt)
+//   -> extend rounds (mem_chain2aln/ksw_extend2) -> dedup (mem_sort_dedup_patch)          == mem_align1_core x2
+//   -> rescue rounds (mem_matesw/ksw_align2)                                             == the two rescue loops
+//   -> reg2aln (mem_reg2aln/bwa_gen_cigar2/ksw_global2) for every surviving region.
+#pragma once
+#include <vector>
+#include <string>
+#include <cstring>
+#include "arx_dev.h"
+#include "dev_fm.h"
+#include "dev_chain.h"
+#include "dev_sw.h"
+#include "dev_regs.h"
+
+namespace arx {
+
+// ---------------------------------------------------------------- kernel functors (item = work unit, slot = scratch slot)
+struct KSeed {
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens;
+	Biv *intv; int32_t *n_intv, *n_occ; Biv *scratch; int list_cap; uint32_t *err;
+	ARX_DEV void operator()(int r, int slot) const
+	{
+		int len = lens[r], ovf = 0, n = 0, occ = 0;
+		if (len > MAX_READ_LEN) { atomic_or_err(err, ERR_READ_TOO_LONG); len = 0; }
+		if (len >= OPT_MIN_SEED_LEN) {
+			SmemScratch sc; sc.v0 = scratch + (size_t)slot * 3 * list_cap; sc.v1 = sc.v0 + list_cap; sc.mem = sc.v1 + list_cap;
+			Biv *out = intv + (size_t)r * CAP_INTV;
+			n = collect_intv(ix, len, bases + base_off[r], sc, out, CAP_INTV, &ovf);
+			for (int i = 0; i < n; ++i) occ += out[i].s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)out[i].s;
+		}
+		if (ovf) atomic_or_err(err, ERR_INTV_OVERFLOW);
+		n_intv[r] = n; n_occ[r] = occ;
+	}
+	static ARX_DEVI void atomic_or_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); }
+};
+
+// one thread per seed occurrence: which read / interval / rank, then the sampled-SA walk (bwamem.c:273-283)
+struct KLocate {
+	IndexView ix; const Biv *intv; const int32_t *n_intv; const int32_t *occ_off; int n_reads; Seed *occ_seed;
+	ARX_DEV void operator()(int g, int) const
+	{
+		int lo = 0, hi = n_reads; // last r with occ_off[r] <= g
+		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (occ_off[mid] <= g) lo = mid; else hi = mid; }
+		const int r = lo;
+		int local = g - occ_off[r];
+		const Biv *iv = intv + (size_t)r * CAP_INTV;
+		for (int i = 0; i < n_intv[r]; ++i) {
+			const Biv p = iv[i];
+			int cnt = p.s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)p.s;
+			if (local < cnt) {
+				uint64_t step = p.s > (uint64_t)OPT_MAX_OCC ? p.s / OPT_MAX_OCC : 1;
+				Seed s;
+				s.rbeg = (int64_t)sa_lookup(ix, p.k + (uint64_t)local * step);
+				s.qbeg = (int32_t)(p.info >> 32);
+				s.len = (int32_t)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+				occ_seed[g] = s;
+				return;
+			}
+			local -= cnt;
+		}
+	}
+};
+
+struct KChain {
+	IndexView ix; const int32_t *lens; const Biv *intv; const int32_t *n_intv, *occ_off; const Seed *occ_seed;
+	int32_t *next; Chain *ctmp; BtNode *nodes; int32_t *iscr; Chain *cout; Seed *sout; int32_t *n_chain; uint32_t *err;
+	ARX_DEV void operator()(int r, int) const
+	{
+		const int g0 = occ_off[r], n = occ_off[r + 1] - g0;
+		const int node0 = g0 / 3 + 4 * r, node1 = occ_off[r + 1] / 3 + 4 * (r + 1);
+		int m = chain_and_filter(ix, lens[r], intv + (size_t)r * CAP_INTV, n_intv[r], occ_seed + g0, n, next + g0, ctmp + g0,
+		                         nodes + node0, node1 - node0, iscr + 2 * (size_t)g0, cout + g0, sout + g0, g0);
+		if (m < 0) { KSeed::atomic_or_err(err, ERR_POOL_OVERFLOW); m = 0; }
+		n_chain[r] = m;
+	}
+};
+
+struct KExtStep {
+	IndexView ix; const int32_t *base_off, *lens, *occ_off, *n_chain; const Chain *chains; const Seed *seeds; int32_t *srt; Reg *regs;
+	ExtState *state; const ExtRes *res; ExtTask *tasks; int32_t *n_tasks; int first;
+	ARX_DEV void operator()(int r, int) const
+	{
+		ExtState st;
+		if (first) { st = ExtState(); st.ci = -1; st.k = -1; st.phase = PH_PICK; st.n_regs = 0; }
+		else { st = state[r]; if (st.phase == PH_DONE) return; }
+		ExtTask t;
+		const int g0 = occ_off[r];
+		ExtRes rs = first ? ExtRes() : res[r];
+		bool more = ext_step(ix, r, base_off[r], lens[r], chains + g0, n_chain[r], seeds, srt, regs + g0, st, rs, t);
+		state[r] = st;
+		if (more) tasks[claim(n_tasks)] = t;
+	}
+	static ARX_DEVI int claim(int32_t *ctr) { return ARX_ATOMIC_INC(ctr); }
+};
+
+struct KExtend {
+	IndexView ix; const uint8_t *bases; const ExtTask *tasks; ExtRes *res;
+	ARX_DEV void operator()(int i, int, uint32_t *row, int stride) const
+	{
+		const ExtTask t = tasks[i];
+		res[t.owner] = ext2_task(ix, bases, t, row, stride);
+	}
+};
+
+struct KDedup {
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const ExtState *state; Reg *regs, *tmp; int32_t *idx;
+	int32_t *eh; int eh_words; int32_t *n_core;
+	ARX_DEV void operator()(int r, int slot) const
+	{
+		const int g0 = occ_off[r];
+		int n = state[r].n_regs;
+		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
+		for (int i = 0; i < n; ++i) { Reg &p = regs[g0 + i]; if (p.rid >= 0 && ix.ann_alt[p.rid]) p.is_alt = 1; }
+		n_core[r] = n;
+	}
+};
+
+// capacity of each read's final region list: core regions + one rescue per eligible anchor of the mate (<= 50)
+struct KPairCap {
+	const int32_t *n_core; int32_t *cap;
+	ARX_DEV void operator()(int p, int) const
+	{
+		int n0 = n_core[2 * p], n1 = n_core[2 * p + 1];
+		int c0 = n0 + (n1 < MAX_RESCUE ? n1 : MAX_RESCUE);
+		int c1 = n1 + (c0 < MAX_RESCUE ? c0 : MAX_RESCUE);
+		cap[2 * p] = c0 + 1; cap[2 * p + 1] = c1 + 1;
+	}
+};
+
+struct KPairInit {
+	const int32_t *occ_off, *n_core, *preg_off; const Reg *regs; Reg *pregs; int32_t *n_regs; ResState *state;
+	ARX_DEV void operator()(int p, int) const
+	{
+		ResState st = ResState();
+		for (int e = 0; e < 2; ++e) {
+			const int r = 2 * p + e, n = n_core[r];
+			int best = 0;
+			for (int i = 0; i < n; ++i) { Reg x = regs[occ_off[r] + i]; pregs[preg_off[r] + i] = x; if (x.score > best) best = x.score; }
+			n_regs[r] = n; st.best[e] = best;
+		}
+		st.e = 1; st.i = 0; st.num = 0; st.n_snap = n_core[2 * p + 1]; st.phase = 0; // first loop: anchors = read 2's hits
+		state[p] = st;
+	}
+};
+
+struct KRescueStep {
+	IndexView ix; const int32_t *lens, *preg_off; Reg *pregs, *ptmp; int32_t *pidx, *n_regs; ResState *state; const U8Res *res; SwTask *tasks; int32_t *n_tasks;
+	ARX_DEV void operator()(int p, int) const
+	{
+		ResState st = state[p];
+		if (st.phase == 2) return;
+		Reg *rg[2] = { pregs + preg_off[2 * p], pregs + preg_off[2 * p + 1] };
+		Reg *tm[2] = { ptmp + preg_off[2 * p], ptmp + preg_off[2 * p + 1] };
+		int *ix2[2] = { pidx + preg_off[2 * p], pidx + preg_off[2 * p + 1] };
+		int *nr[2] = { n_regs + 2 * p, n_regs + 2 * p + 1 };
+		SwTask t;
+		bool more = rescue_step(ix, p, lens + 2 * p, rg, nr, tm, ix2, st, res[p], t);
+		state[p] = st;
+		if (more) tasks[KExtStep::claim(n_tasks)] = t;
+	}
+};
+
+struct KSwU8 {
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; const SwTask *tasks; U8Res *res; uint8_t *scratch; int q_cap, t_cap;
+	ARX_DEV void operator()(int i, int slot, uint32_t *row, int stride) const
+	{
+		const SwTask t = tasks[i];
+		const int r = 2 * t.pair + t.o, l_ms = lens[r], tlen = (int)(t.re - t.rb);
+		uint8_t *qbuf = scratch + (size_t)slot * (q_cap + 2 * t_cap), *tbuf = qbuf + q_cap, *rowmax = tbuf + t_cap;
+		const uint8_t *ms = bases + base_off[r];
+		for (int k = 0; k < l_ms; ++k) { int b = ms[k]; qbuf[l_ms - 1 - k] = b < 4 ? 3 - b : 4; } // reverse complement of the mate (bwamem_pair.c:134-137)
+		for (int k = 0; k < tlen; ++k) tbuf[k] = (uint8_t)ref_base(ix, t.rb + k);
+		res[t.pair] = u8_align(qbuf, l_ms, tbuf, tlen, KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A), row, stride, rowmax);
+	}
+};
+
+struct KReg2Aln {
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *preg_off, *n_regs; int n_reads; const Reg *pregs;
+	Aln *alns; uint32_t *cig; int cig_w; int32_t *eh; int eh_words; uint8_t *z; int z_cap; uint32_t *err;
+	ARX_DEV void operator()(int g, int slot) const
+	{
+		int lo = 0, hi = n_reads;
+		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (preg_off[mid] <= g) lo = mid; else hi = mid; }
+		const int r = lo, j = g - preg_off[r];
+		if (j >= n_regs[r]) return;
+		const Reg ar = pregs[g];
+		Aln a = Aln();
+		a.cigar_off = g * cig_w;
+		const int lq = lens[r];
+		// worst-case traceback matrix for this region: n_col <= l_query, rows = re - rb
+		if ((int64_t)(ar.qe - ar.qb) * (ar.re - ar.rb) > z_cap) { KSeed::atomic_or_err(err, ERR_POOL_OVERFLOW); a.n_cigar = 0; a.rid = -1; alns[g] = a; return; }
+		if (!reg2aln(ix, lq, bases + base_off[r], ar, eh + (size_t)slot * eh_words, z + (size_t)slot * z_cap, cig + (size_t)g * cig_w, cig_w, a))
+			KSeed::atomic_or_err(err, ERR_CIGAR_OVERFLOW);
+		alns[g] = a;
+	}
+};
+
+// ---------------------------------------------------------------- batch containers
+struct BatchResult { // host copies, flat (reads in input order; region rows in list order)
+	std::vector<int32_t> reg_off;   // n_reads + 1
+	std::vector<Reg> regs;
+	std::vector<Aln> alns;          // cigar_off indexes `cigars`
+	std::vector<uint32_t> cigars;
+	int ext_rounds = 0, rescue_rounds = 0;
+	int64_t n_occ = 0, n_ext_tasks = 0, n_sw_tasks = 0;
+};
+
+template <class RT> class Pipeline {
+public:
+	RT &rt;
+	IndexView ix;
+	explicit Pipeline(RT &rt_, const IndexView &ix_) : rt(rt_), ix(ix_) {}
+
+	// device-resident input of one batch
+	struct DeviceBatch { uint8_t *bases = 0; int32_t *base_off = 0, *lens = 0; int n_reads = 0; int64_t n_bases = 0; int max_len = 0; };
+
+	DeviceBatch upload(const uint8_t *bases, const int32_t *lens, int n_reads)
+	{
+		DeviceBatch b;
+		std::vector<int32_t> off(n_reads + 1);
+		int64_t tot = 0; int mx = 0;
+		for (int i = 0; i < n_reads; ++i) { off[i] = (int32_t)tot; tot += lens[i]; if (lens[i] > mx) mx = lens[i]; }
+		off[n_reads] = (int32_t)tot;
+		b.n_reads = n_reads; b.n_bases = tot; b.max_len = mx;
+		b.bases = rt.template alloc<uint8_t>(tot + 16);
+		b.base_off = rt.template alloc<int32_t>(n_reads + 1);
+		b.lens = rt.template alloc<int32_t>(n_reads + 1);
+		rt.h2d(b.bases, bases, tot);
+		rt.h2d(b.base_off, off.data(), sizeof(int32_t) * (n_reads + 1));
+		rt.h2d(b.lens, lens, sizeof(int32_t) * n_reads);
+		return b;
+	}
+	void release(DeviceBatch &b) { rt.free(b.bases); rt.free(b.base_off); rt.free(b.lens); b = DeviceBatch(); }
+
+	// everything that stays on the device between the stages of one batch
+	struct Work {
+		Biv *intv = 0, *smem_scr = 0; int32_t *n_intv = 0, *n_occ = 0, *occ_off = 0; Seed *occ_seed = 0;
+		int32_t *next = 0, *iscr = 0, *n_chain = 0, *srt = 0, *idx = 0, *n_core = 0; Chain *ctmp = 0, *cout = 0; BtNode *nodes = 0; Seed *sout = 0;
+		Reg *regs = 0, *rtmp = 0; ExtState *est = 0; ExtTask *etask = 0; ExtRes *eres = 0; int32_t *counter = 0; uint32_t *err = 0;
+		int32_t *eh = 0; int32_t *cap = 0, *preg_off = 0, *n_regs = 0, *pidx = 0; Reg *pregs = 0, *ptmp = 0; ResState *rst = 0; SwTask *stask = 0; U8Res *sres = 0;
+		uint8_t *sw_scr = 0, *z = 0; Aln *alns = 0; uint32_t *cig = 0;
+		int64_t T = 0, P = 0; int cig_w = 0;
+	};
+
+	void free_work(Work &w)
+	{
+		void *ptrs[] = { w.intv, w.smem_scr, w.n_intv, w.n_occ, w.occ_off, w.occ_seed, w.next, w.iscr, w.n_chain, w.srt, w.idx, w.n_core, w.ctmp, w.cout,
+		                 w.nodes, w.sout, w.regs, w.rtmp, w.est, w.etask, w.eres, w.counter, w.err, w.eh, w.cap, w.preg_off, w.n_regs, w.pidx, w.pregs,
+		                 w.ptmp, w.rst, w.stask, w.sres, w.sw_scr, w.z, w.alns, w.cig };
+		for (void *p : ptrs) if (p) rt.free(p);
+		w = Work();
+	}
+
+	uint32_t read_err(Work &w) { uint32_t e = 0; rt.d2h(&e, w.err, 4); return e; }
+	int32_t read_counter(Work &w) { int32_t c = 0; rt.d2h(&c, w.counter, 4); return c; }
+
+	// ---- stage 1+2: seeding and locate.  Leaves intervals and located seeds on the device.
+	int stage_seed(const DeviceBatch &b, Work &w)
+	{
+		const int R = b.n_reads, slots = rt.max_slots(), list_cap = b.max_len + 2;
+		w.err = rt.template alloc<uint32_t>(4); rt.memset0(w.err, 16);
+		w.counter = rt.template alloc<int32_t>(4);
+		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);
+		w.smem_scr = rt.template alloc<Biv>((size_t)slots * 3 * list_cap);
+		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
+		KSeed k{ix, b.bases, b.base_off, b.lens, w.intv, w.n_intv, w.n_occ, w.smem_scr, list_cap, w.err};
+		rt.launch("seed", R, k);
+		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R);
+		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
+		w.T = total;
+		w.occ_seed = rt.template alloc<Seed>(w.T + 1);
+		if (w.T) { KLocate kl{ix, w.intv, w.n_intv, w.occ_off, R, w.occ_seed}; rt.launch("locate", (int)w.T, kl); }
+		return 0;
+	}
+
+	// ---- stage 3: chaining and chain filtering
+	void stage_chain(const DeviceBatch &b, Work &w)
+	{
+		const int R = b.n_reads; const size_t T = (size_t)w.T + 1;
+		w.next = rt.template alloc<int32_t>(T); w.ctmp = rt.template alloc<Chain>(T); w.cout = rt.template alloc<Chain>(T);
+		w.nodes = rt.template alloc<BtNode>(T / 3 + 4 * (size_t)R + 8); w.iscr = rt.template alloc<int32_t>(2 * T); w.sout = rt.template alloc<Seed>(T);
+		w.n_chain = rt.template alloc<int32_t>(R + 1);
+		KChain k{ix, b.lens, w.intv, w.n_intv, w.occ_off, w.occ_seed, w.next, w.ctmp, w.nodes, w.iscr, w.cout, w.sout, w.n_chain, w.err};
+		rt.launch("chain", R, k);
+	}
+
+	// ---- stage 4: extension rounds, then de-duplication -> core regions of every read
+	void stage_extend(const DeviceBatch &b, Work &w, BatchResult &out)
+	{
+		const int R = b.n_reads; const size_t T = (size_t)w.T + 1; const int slots = rt.max_slots();
+		w.srt = rt.template alloc<int32_t>(T); w.regs = rt.template alloc<Reg>(T); w.rtmp = rt.template alloc<Reg>(T); w.idx = rt.template alloc<int32_t>(T);
+		w.est = rt.template alloc<ExtState>(R + 1); w.etask = rt.template alloc<ExtTask>(R + 1); w.eres = rt.template alloc<ExtRes>(R + 1);
+		w.n_core = rt.template alloc<int32_t>(R + 1);
+		const int eh_words = 2 * (b.max_len + 2);
+		w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
+		for (int round = 0;; ++round) {
+			rt.memset0(w.counter, 4);
+			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, w.n_chain, w.cout, w.sout, w.srt, w.regs, w.est, w.eres, w.etask, w.counter, round == 0};
+			rt.launch("ext_step", R, ks);
+			int nt = read_counter(w);
+			if (nt == 0) break;
+			out.n_ext_tasks += nt; ++out.ext_rounds;
+			KExtend ke{ix, b.bases, w.etask, w.eres};
+			rt.launch_rows("extend", nt, ke, b.max_len + 1);
+		}
+		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, w.est, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core};
+		rt.launch("dedup", R, kd);
+	}
+
+	// ---- stage 5: mate rescue rounds
+	void stage_rescue(const DeviceBatch &b, Work &w, BatchResult &out)
+	{
+		const int R = b.n_reads, NP = R / 2, slots = rt.max_slots();
+		w.cap = rt.template alloc<int32_t>(R + 1); w.preg_off = rt.template alloc<int32_t>(R + 2); w.n_regs = rt.template alloc<int32_t>(R + 1);
+		KPairCap kc{w.n_core, w.cap};
+		rt.launch("pair_cap", NP, kc);
+		w.P = rt.exclusive_scan(w.cap, w.preg_off, R);
+		const size_t P = (size_t)w.P + 1;
+		w.pregs = rt.template alloc<Reg>(P); w.ptmp = rt.template alloc<Reg>(P); w.pidx = rt.template alloc<int32_t>(P);
+		w.rst = rt.template alloc<ResState>(NP + 1); w.stask = rt.template alloc<SwTask>(NP + 1); w.sres = rt.template alloc<U8Res>(NP + 1);
+		const int q_cap = (b.max_len + 15) & ~15, t_cap = (PES_HIGH - PES_LOW + 2 * b.max_len + 31) & ~15;
+		w.sw_scr = rt.template alloc<uint8_t>((size_t)slots * (q_cap + 2 * t_cap));
+		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst};
+		rt.launch("pair_init", NP, ki);
+		for (int round = 0;; ++round) {
+			rt.memset0(w.counter, 4);
+			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter};
+			rt.launch("rescue_step", NP, ks);
+			int nt = read_counter(w);
+			if (nt == 0) break;
+			out.n_sw_tasks += nt; ++out.rescue_rounds;
+			KSwU8 kw{ix, b.bases, b.base_off, b.lens, w.stask, w.sres, w.sw_scr, q_cap, t_cap};
+			rt.launch_rows("sw_u8", nt, kw, 16 * ((b.max_len + 15) / 16));
+		}
+	}
+
+	// ---- stage 6: CIGAR for every region; retried with wider CIGAR slots if one overflows
+	int stage_reg2aln(const DeviceBatch &b, Work &w)
+	{
+		const int slots = rt.max_slots_small();
+		const int eh_words = 2 * (b.max_len + 2);
+		const int z_cap = b.max_len * (2 * b.max_len + 64);
+		const size_t P = (size_t)w.P + 1;
+		w.z = rt.template alloc<uint8_t>((size_t)slots * z_cap);
+		rt.free(w.eh); w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
+		w.alns = rt.template alloc<Aln>(P);
+		for (w.cig_w = 16;; w.cig_w *= 2) {
+			if (w.cig) rt.free(w.cig);
+			w.cig = rt.template alloc<uint32_t>(P * w.cig_w);
+			KReg2Aln k{ix, b.bases, b.base_off, b.lens, w.preg_off, w.n_regs, b.n_reads, w.pregs, w.alns, w.cig, w.cig_w, w.eh, eh_words, w.z, z_cap, w.err};
+			rt.launch_small("reg2aln", (int)w.P, k);
+			uint32_t e = read_err(w);
+			if (!(e & ERR_CIGAR_OVERFLOW)) return (int)e;
+			if (w.cig_w >= 1024) return (int)e;
+			e &= ~ERR_CIGAR_OVERFLOW; rt.h2d(w.err, &e, 4);
+		}
+	}
+
+	// ---- whole path for one batch (n_reads even: read 2i / 2i+1 are mates).  Returns 0 or an error bit set.
+	int run(const DeviceBatch &b, BatchResult &out, Work &w)
+	{
+		int rc = stage_seed(b, w);
+		if (rc) return rc;
+		stage_chain(b, w);
+		stage_extend(b, w, out);
+		stage_rescue(b, w, out);
+		rc = stage_reg2aln(b, w);
+		out.n_occ = w.T;
+		return rc;
+	}
+
+	// copy the final region lists and alignment records to the host, compacted
+	void download(const DeviceBatch &b, Work &w, BatchResult &out)
+	{
+		const int R = b.n_reads; const size_t P = (size_t)w.P;
+		std::vector<int32_t> off(R + 1), n(R);
+		std::vector<Reg> pr(P + 1); std::vector<Aln> pa(P + 1); std::vector<uint32_t> cg((P + 1) * w.cig_w);
+		rt.d2h(off.data(), w.preg_off, 4 * (R + 1)); rt.d2h(n.data(), w.n_regs, 4 * R);
+		rt.d2h(pr.data(), w.pregs, sizeof(Reg) * P); rt.d2h(pa.data(), w.alns, sizeof(Aln) * P); rt.d2h(cg.data(), w.cig, 4 * P * w.cig_w);
+		out.reg_off.assign(R + 1, 0); out.regs.clear(); out.alns.clear(); out.cigars.clear();
+		for (int r = 0; r < R; ++r) {
+			out.reg_off[r] = (int32_t)out.regs.size();
+			for (int j = 0; j < n[r]; ++j) {
+				const size_t g = (size_t)off[r] + j;
+				Aln a = pa[g];
+				const uint32_t *c = cg.data() + g * w.cig_w;
+				a.cigar_off = (int32_t)out.cigars.size();
+				out.cigars.insert(out.cigars.end(), c, c + a.n_cigar);
+				out.regs.push_back(pr[g]); out.alns.push_back(a);
+			}
+		}
+		out.reg_off[R] = (int32_t)out.regs.size();
+	}
+};
+
+} // namespace arx

@@ -1,0 +1,86 @@
+/*
+ * arachne_amd.h -- C ABI of libarachne_amd.so, the MI355X (gfx950) implementation of Arachne's per-barcode
+ * alignment hot path.  Plain pointers and sizes only; no torch / HIP types cross this boundary.
+ *
+ * What it replaces in the reference (pdimens/arachne @ 2025-09-05), whose Go code reaches the BWA C core one
+ * read / one candidate at a time through cgo (src/gobwa/gobwa.go:7-13, src/gobwa/bwa_bridge.h:35-39):
+ *
+ *   arx_open           <- bwa_idx_load(path, BWA_IDX_ALL) + mem_opt_init()      gobwa.go:128-152 (GoBwaLoadReference, GoBwaAllocSettings)
+ *   arx_contigs        <- direct field reads of bwaidx_t.bns / bntann1_t        gobwa.go:28-39,420-432 (GetReferenceContigsInfo, EnumerateContigs)
+ *   arx_batch_create   <- SequenceConvert (nst_nt4_table) per read              gobwa.go:159-167; the caller passes 0..4 codes
+ *   arx_batch_run      <- per pair: mem_align1_core x2, the two mem_matesw loops, InterpretAlign           gobwa.go:226-337 (GoBwaMemMateSW)
+ *                         per candidate: mem_reg2aln                                                      gobwa.go:400-415 (GoBwaSmithWaterman)
+ *                         i.e. loops A and B of DoRFAForOneBarcode               src/aligner/aligner.go:1633-1715,1484-1501
+ *   arx_batch_fetch    <- mem_alnreg_v / mem_aln_t returned by value + Arena     gobwa.go:107-126,191,326-327,411-412
+ *   arx_batch_free     <- Arena.Free                                             aligner.go:475,500
+ *
+ * Errors: every entry returns ARX_OK (0) or a negative code and never aborts the process (the reference asserts /
+ * err_fatals); arx_last_error() gives the text.  A context may be shared by threads that each own their batches.
+ * Results are bit-identical to the reference C core: same regions in the same order, same CIGAR/NM/pos/strand.
+ */
+#ifndef ARACHNE_AMD_H
+#define ARACHNE_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct arx_ctx arx_ctx;
+typedef struct arx_batch arx_batch;
+
+enum { ARX_OK = 0, ARX_E_OPEN = -1, ARX_E_ARG = -2, ARX_E_DEVICE = -3, ARX_E_TOO_LARGE = -4 };
+
+/* last_stage values for arx_batch_run: stop after a stage to inspect intermediate results */
+enum { ARX_STAGE_SEED = 1, ARX_STAGE_CHAIN = 2, ARX_STAGE_EXTEND = 3, ARX_STAGE_RESCUE = 4, ARX_STAGE_ALN = 5 };
+
+/* mem_alnreg_t (bwa/bwamem.h:66-87) without `hash` (always 0 on this path); frac_rep keeps its float bits */
+typedef struct {
+	int64_t rb, re;                 /* [rb,re) on the forward+reverse reference */
+	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
+	float frac_rep;
+	int32_t pad;
+} arx_reg;
+
+/* mem_aln_t (bwa/bwamem.h:97-108) without XA and mapq (never read by Arachne) */
+typedef struct {
+	int64_t pos;                    /* 0-based leftmost position on contig rid */
+	int32_t rid, flag, is_rev, is_alt, NM, n_cigar, cigar_off /* into the cigar array of the batch */, score, sub, alt_sc;
+} arx_aln;
+
+typedef struct { int64_t pos; int32_t rid, n, seed_off, w, kept, first, is_alt, head, tail; float frac_rep; } arx_chain; /* mem_chain_t */
+typedef struct { int64_t rbeg; int32_t qbeg, len; } arx_seed;                                                         /* mem_seed_t  */
+
+/* Loads <prefix>.{bwt,sa,pac,ann,amb,alt} (files written by `bwa index`) into HBM of `device`. */
+int arx_open(const char *prefix, int device, arx_ctx **out);
+void arx_close(arx_ctx *ctx);
+const char *arx_last_error(arx_ctx *ctx);      /* ctx may be NULL after a failed arx_open */
+const char *arx_backend(void);                 /* "hip:gfx950" for the product library */
+
+int arx_contigs(arx_ctx *ctx, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens,
+                const int32_t **is_alt, int64_t *l_pac);
+
+/* bases: concatenated reads as codes 0..4 (A,C,G,T,N); lens[n_reads]; read 2i and 2i+1 are mates (either may be empty).
+ * Reads of one barcode are contiguous; barcode boundaries do not matter to this stage (pairs are independent). */
+int arx_batch_create(arx_ctx *ctx, int32_t n_reads, const uint8_t *bases, const int32_t *lens, arx_batch **out);
+int arx_batch_run(arx_ctx *ctx, arx_batch *b, int32_t last_stage);
+/* counts[8] = n_reads, n_regs, n_cigar_words, seed occurrences, extension rounds, extension DPs, rescue rounds, rescue SWs */
+int arx_batch_counts(arx_ctx *ctx, arx_batch *b, int64_t *counts);
+/* reg_off[n_reads+1], regs[n_regs], alns[n_regs], cigars[n_cigar_words]: caller-allocated from arx_batch_counts */
+int arx_batch_fetch(arx_ctx *ctx, arx_batch *b, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars);
+void arx_batch_free(arx_ctx *ctx, arx_batch *b);
+
+/* intermediate results for parity tests (device -> host copies of stage outputs) */
+#define ARX_CAP_INTV 256
+int arx_batch_debug_intv(arx_ctx *ctx, arx_batch *b, int32_t *n_intv, uint64_t *intv4 /* n_reads*ARX_CAP_INTV*4 */);
+int arx_batch_debug_chains(arx_ctx *ctx, arx_batch *b, int32_t *occ_off /* n_reads+1 */, int32_t *n_chain, arx_chain *chains, arx_seed *seeds /* counts[3] each */);
+int arx_batch_debug_core(arx_ctx *ctx, arx_batch *b, int32_t *n_core, arx_reg *regs /* counts[3] */);
+
+/* per-kernel device time (HIP events on the launch stream), accumulated since the last reset */
+int arx_kernel_times(arx_ctx *ctx, int32_t cap, char *names, int32_t name_w, double *ms, int64_t *calls, int64_t *items);
+void arx_kernel_times_reset(arx_ctx *ctx, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
