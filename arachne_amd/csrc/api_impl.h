@@ -108,7 +108,7 @@ template <class RT> struct Batch {
 	int arx_batch_counts(arx_ctx *, arx_batch *bh, int64_t *c8)                                                                     \
 	{                                                                                                                               \
 		Bat *b = (Bat *)bh;                                                                                                         \
-		if (b->work.pregs && !b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                    \
+		if (b->work.alns && !b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                     \
 		c8[0] = b->db.n_reads; c8[1] = (int64_t)b->res.regs.size(); c8[2] = (int64_t)b->res.cigars.size(); c8[3] = b->res.n_occ;    \
 		c8[4] = b->res.ext_rounds; c8[5] = b->res.n_ext_tasks; c8[6] = b->res.rescue_rounds; c8[7] = b->res.n_sw_tasks;             \
 		return ARX_OK;                                                                                                              \
@@ -116,7 +116,7 @@ template <class RT> struct Batch {
 	int arx_batch_fetch(arx_ctx *, arx_batch *bh, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars)                 \
 	{                                                                                                                               \
 		Bat *b = (Bat *)bh;                                                                                                         \
-		if (!b->work.pregs) return ARX_E_ARG;                                                                                       \
+		if (!b->work.alns) return ARX_E_ARG;                                                                                        \
 		if (!b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                                     \
 		static_assert(sizeof(arx_reg) == sizeof(arx::Reg) && sizeof(arx_aln) == sizeof(arx::Aln), "C-ABI structs must mirror the device structs"); \
 		memcpy(reg_off, b->res.reg_off.data(), 4 * b->res.reg_off.size());                                                          \

@@ -204,7 +204,11 @@ struct RegScoreLt {
 	}
 };
 
-template <class LT> ARX_DEV void permute_regs(int n, Reg *a, Reg *tmp, int *idx, LT lt)
+template <class LT>
+#ifdef ARX_OPTNONE_PERMUTE
+__attribute__((optnone, noinline))
+#endif
+ARX_DEV void permute_regs(int n, Reg *a, Reg *tmp, int *idx, LT lt)
 {
 	for (int i = 0; i < n; ++i) idx[i] = i;
 	ks_introsort(n, idx, lt);
@@ -235,6 +239,9 @@ ARX_DEV int patch_reg(const IndexView &ix, const uint8_t *query, const Reg &a, c
 	return score;
 }
 
+#ifdef ARX_OPTNONE_DEDUP
+__attribute__((optnone, noinline))
+#endif
 ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, Reg *a, Reg *tmp, int *idx, int32_t *eh)
 {
 	int m, i, j;
@@ -243,41 +250,45 @@ ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, R
 	permute_regs(n, a, tmp, idx, lt1);
 	for (i = 0; i < n; ++i) a[i].n_comp = 1;
 	for (i = 1; i < n; ++i) {
-		Reg &p = a[i];
-		if (p.rid != a[i - 1].rid || p.rb >= a[i - 1].re + OPT_MAX_CHAIN_GAP) continue;
-		for (j = i - 1; j >= 0 && p.rid == a[j].rid && p.rb < a[j].re + OPT_MAX_CHAIN_GAP; --j) {
-			Reg &q = a[j];
-			int64_t orr, oq, mr, mq;
-			int score, w;
-			if (q.qe == q.qb) continue;
-			orr = q.re - p.rb;
-			oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
-			mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
-			mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
-			if ((float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq) {
-				if (p.score < q.score) { p.qe = p.qb; break; }
-				else q.qe = q.qb;
-			} else if (q.rb < p.rb && (score = patch_reg(ix, query, q, p, eh, &w)) > 0) {
-				p.n_comp += q.n_comp + 1;
-				p.seedcov = p.seedcov > q.seedcov ? p.seedcov : q.seedcov;
-				p.sub = p.sub > q.sub ? p.sub : q.sub;
-				p.csub = p.csub > q.csub ? p.csub : q.csub;
-				p.qb = q.qb; p.rb = q.rb;
-				p.truesc = p.score = score;
-				p.w = w;
-				q.qb = q.qe;
+		// structured form of the reference's loop (bwamem.c:443-473): `live` replaces its continue/break exits
+		bool live = !(a[i].rid != a[i - 1].rid || a[i].rb >= a[i - 1].re + OPT_MAX_CHAIN_GAP);
+		for (j = i - 1; live && j >= 0; --j) {
+			Reg p = a[i], q = a[j];
+			if (!(p.rid == q.rid && p.rb < q.re + OPT_MAX_CHAIN_GAP)) { live = false; }
+			else if (q.qe != q.qb) { // a[j] has not been excluded
+				int64_t orr = q.re - p.rb;
+				int64_t oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+				int64_t mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+				int64_t mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+				int score = 0, w = 0;
+				if ((float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq) {
+					if (p.score < q.score) { a[i].qe = p.qb; live = false; }
+					else a[j].qe = q.qb;
+				} else if (q.rb < p.rb && (score = patch_reg(ix, query, q, p, eh, &w)) > 0) {
+					p.n_comp += q.n_comp + 1;
+					p.seedcov = p.seedcov > q.seedcov ? p.seedcov : q.seedcov;
+					p.sub = p.sub > q.sub ? p.sub : q.sub;
+					p.csub = p.csub > q.csub ? p.csub : q.csub;
+					p.qb = q.qb; p.rb = q.rb;
+					p.truesc = p.score = score;
+					p.w = w;
+					a[i] = p;
+					a[j].qb = q.qe;
+				}
 			}
 		}
 	}
-	for (i = 0, m = 0; i < n; ++i)
-		if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+	m = 0;
+	for (i = 0; i < n; ++i)
+		if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
 	n = m;
 	RegScoreLt lt2; lt2.r = a;
 	permute_regs(n, a, tmp, idx, lt2);
 	for (i = 1; i < n; ++i)
 		if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb) a[i].qe = a[i].qb;
-	for (i = 1, m = 1; i < n; ++i)
-		if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+	m = n > 0 ? 1 : 0;
+	for (i = 1; i < n; ++i)
+		if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
 	return m;
 }
 

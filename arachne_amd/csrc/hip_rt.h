@@ -95,6 +95,17 @@ struct HipRT {
 		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
+	// "cold" kernels (list bookkeeping: dedup, rescue_step) are instantiated in arx_cold.hip, which is compiled at -O1:
+	// hipcc 7.2 at -O2/-O3 emits a dedup kernel that never terminates on gfx950 ("toolchain notes").
+	template <class F> void launch_cold(const char *nm, int n, const F &f);
+	template <class F> void launch_cold_impl(const char *nm, int n, const F &f)
+	{
+		if (n <= 0) return;
+		Scope sc(*this, nm, n);
+		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
+		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
 	template <class F> void launch_small(const char *nm, int n, const F &f)
 	{
 		if (n <= 0) return;

@@ -11,6 +11,8 @@
 #include <vector>
 #include <string>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include "arx_dev.h"
 #include "dev_fm.h"
 #include "dev_chain.h"
@@ -109,12 +111,14 @@ struct KExtend {
 
 struct KDedup {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const ExtState *state; Reg *regs, *tmp; int32_t *idx;
-	int32_t *eh; int eh_words; int32_t *n_core;
+	int32_t *eh; int eh_words; int32_t *n_core; int dbg;
 	ARX_DEV void operator()(int r, int slot) const
 	{
 		const int g0 = occ_off[r];
 		int n = state[r].n_regs;
-		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
+		if (dbg & 4) { n_core[r] = n; return; }
+		if (dbg & 2) { RegReLt lt1; lt1.r = regs + g0; permute_regs(n, regs + g0, tmp + g0, idx + g0, lt1); n_core[r] = n; return; }
+		n = sort_dedup_patch(ix, (dbg & 1) ? (const uint8_t *)0 : bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
 		for (int i = 0; i < n; ++i) { Reg &p = regs[g0 + i]; if (p.rid >= 0 && ix.ann_alt[p.rid]) p.is_alt = 1; }
 		n_core[r] = n;
 	}
@@ -214,6 +218,7 @@ template <class RT> class Pipeline {
 public:
 	RT &rt;
 	IndexView ix;
+	bool trace = getenv("ARX_TRACE") != nullptr; // per-round progress on stderr
 	explicit Pipeline(RT &rt_, const IndexView &ix_) : rt(rt_), ix(ix_) {}
 
 	// device-resident input of one batch
@@ -303,13 +308,17 @@ public:
 			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, w.n_chain, w.cout, w.sout, w.srt, w.regs, w.est, w.eres, w.etask, w.counter, round == 0};
 			rt.launch("ext_step", R, ks);
 			int nt = read_counter(w);
+			if (trace) { fprintf(stderr, "[arx] ext round %d: %d tasks\n", round, nt); fflush(stderr); }
 			if (nt == 0) break;
+			if (round > w.T + R + 8) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; } // cannot happen: every round retires a DP
 			out.n_ext_tasks += nt; ++out.ext_rounds;
 			KExtend ke{ix, b.bases, w.etask, w.eres};
 			rt.launch_rows("extend", nt, ke, b.max_len + 1);
+			if (trace) { rt.sync(); fprintf(stderr, "[arx]   extend kernel done\n"); fflush(stderr); }
 		}
-		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, w.est, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core};
-		rt.launch("dedup", R, kd);
+		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
+		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, w.est, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, getenv("ARX_DEDUP_DBG") ? atoi(getenv("ARX_DEDUP_DBG")) : 0};
+		rt.launch_cold("dedup", R, kd);
 	}
 
 	// ---- stage 5: mate rescue rounds
@@ -330,9 +339,11 @@ public:
 		for (int round = 0;; ++round) {
 			rt.memset0(w.counter, 4);
 			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter};
-			rt.launch("rescue_step", NP, ks);
+			rt.launch_cold("rescue_step", NP, ks);
 			int nt = read_counter(w);
+			if (trace) { fprintf(stderr, "[arx] rescue round %d: %d tasks\n", round, nt); fflush(stderr); }
 			if (nt == 0) break;
+			if (round > 2 * MAX_RESCUE + 4) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; }
 			out.n_sw_tasks += nt; ++out.rescue_rounds;
 			KSwU8 kw{ix, b.bases, b.base_off, b.lens, w.stask, w.sres, w.sw_scr, q_cap, t_cap};
 			rt.launch_rows("sw_u8", nt, kw, 16 * ((b.max_len + 15) / 16));

@@ -24,7 +24,8 @@ struct SimRT {
 	static const char *name() { return "hostsim"; }
 	std::map<std::string, KernelTimer> tm;
 	std::string init(int) { return ""; }
-	template <class T> T *alloc(size_t n) { return (T *)calloc(n ? n : 1, sizeof(T)); }
+	// poison fresh memory: hipMalloc does not zero either, so nothing may rely on it
+	template <class T> T *alloc(size_t n) { size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); memset(p, 0xAB, b); return (T *)p; }
 	void free(void *p) { ::free(p); }
 	void h2d(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void d2h(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
@@ -36,6 +37,7 @@ struct SimRT {
 	void timers_reset(bool) { tm.clear(); }
 	template <class F> void launch(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; for (int i = 0; i < n; ++i) f(i, 0); }
 	template <class F> void launch_small(const char *nm, int n, const F &f) { launch(nm, n, f); }
+	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words)
 	{
 		std::vector<uint32_t> row(words + 8);
