@@ -53,6 +53,7 @@ def _load(path):
     lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.arx_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.arx_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, i32]
     lib.arx_close.argtypes = [vp]
     lib.arx_last_error.restype = C.c_char_p
     lib.arx_last_error.argtypes = [vp]
@@ -69,6 +70,14 @@ def _load(path):
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     return lib
+
+
+def index_build(fasta: str, prefix: str, lib_path: str = LIB_PATH) -> None:
+    """`bwa index` equivalent (host side): writes <prefix>.{bwt,sa,pac,ann,amb}, byte-identical to the reference's."""
+    lib = _load(lib_path)
+    msg = C.create_string_buffer(512)
+    if lib.arx_index_build(fasta.encode(), prefix.encode(), msg, 512) != 0:
+        raise ArachneError("arx_index_build: " + msg.value.decode())
 
 
 class Batch:

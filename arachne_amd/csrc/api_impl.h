@@ -6,6 +6,7 @@
 #include <string>
 #include "../../include/arachne_amd.h"
 #include "index_io.h"
+#include "index_build.h"
 #include "pipeline.h"
 
 namespace arx {
@@ -58,6 +59,13 @@ template <class RT> struct Batch {
 	using Bat = arx::Batch<RT>;                                                                                                     \
 	static thread_local std::string g_open_error;                                                                                   \
 	extern "C" {                                                                                                                    \
+	int arx_index_build(const char *fasta, const char *prefix, char *msg, int32_t msg_cap)                                          \
+	{                                                                                                                               \
+		std::string e;                                                                                                              \
+		try { e = arx::build_index(fasta, prefix); } catch (const std::exception &ex) { e = ex.what(); }                            \
+		if (msg && msg_cap > 0) snprintf(msg, msg_cap, "%s", e.c_str());                                                            \
+		return e.empty() ? ARX_OK : ARX_E_OPEN;                                                                                     \
+	}                                                                                                                               \
 	int arx_open(const char *prefix, int device, arx_ctx **out)                                                                     \
 	{                                                                                                                               \
 		*out = 0;                                                                                                                   \

@@ -36,7 +36,6 @@ struct HipRT {
 	int n_cu = 256;
 	bool timing = false;
 	std::map<std::string, KernelTimer> tm;
-	hipEvent_t ev0 = 0, ev1 = 0;
 	void *scan_tmp = 0; size_t scan_tmp_bytes = 0; int64_t *d_total = 0;
 
 	std::string init(int device)
@@ -49,16 +48,15 @@ struct HipRT {
 		if (hipGetDeviceProperties(&p, device) != hipSuccess) return "hipGetDeviceProperties failed";
 		n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 		if (hipStreamCreate(&stream) != hipSuccess) return "hipStreamCreate failed";
-		hipEventCreate(&ev0); hipEventCreate(&ev1);
-		hipMalloc(&d_total, 8);
+		(void)hipMalloc(&d_total, 8);
 		return "";
 	}
 	~HipRT()
 	{
 		if (scan_tmp) hipFree(scan_tmp);
 		if (d_total) hipFree(d_total);
-		if (ev0) hipEventDestroy(ev0);
-		if (ev1) hipEventDestroy(ev1);
+		for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+		for (auto e : free_events) (void)hipEventDestroy(e);
 		if (stream) hipStreamDestroy(stream);
 	}
 	template <class T> T *alloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; }
@@ -73,19 +71,40 @@ struct HipRT {
 	int max_slots() const { return max_blocks() * 64; }
 	int max_slots_small() const { return n_cu * 64; }
 
+	// Kernel timing: a pair of HIP events around each launch on the launch stream, recorded without blocking and
+	// resolved (hipEventElapsedTime) the next time the stream is known to be idle.
+	struct Pending { hipEvent_t a, b; const char *nm; int64_t items; };
+	std::vector<Pending> pending;
+	std::vector<hipEvent_t> free_events;
+	hipEvent_t get_event()
+	{
+		if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+		hipEvent_t e; ARX_HIP_CHECK(hipEventCreate(&e)); return e;
+	}
 	struct Scope {
-		HipRT &rt; const char *nm; int64_t items;
-		Scope(HipRT &r, const char *n, int64_t it) : rt(r), nm(n), items(it) { if (rt.timing) hipEventRecord(rt.ev0, rt.stream); }
-		~Scope()
+		HipRT &rt; Pending p; bool on;
+		Scope(HipRT &r, const char *n, int64_t it) : rt(r), on(r.timing)
 		{
-			if (!rt.timing) return;
-			hipEventRecord(rt.ev1, rt.stream); hipEventSynchronize(rt.ev1);
-			float ms = 0; hipEventElapsedTime(&ms, rt.ev0, rt.ev1);
-			KernelTimer &t = rt.tm[nm]; t.ms += ms; ++t.calls; t.items += items;
+			if (!on) return;
+			p.a = rt.get_event(); p.b = rt.get_event(); p.nm = n; p.items = it;
+			(void)hipEventRecord(p.a, rt.stream);
 		}
+		~Scope() { if (on) { (void)hipEventRecord(p.b, rt.stream); rt.pending.push_back(p); } }
 	};
-	std::map<std::string, KernelTimer> &timers() { return tm; }
-	void timers_reset(bool enable) { tm.clear(); timing = enable; }
+	void resolve_timers()
+	{
+		if (pending.empty()) return;
+		(void)hipStreamSynchronize(stream);
+		for (auto &p : pending) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, p.a, p.b);
+			KernelTimer &t = tm[p.nm]; t.ms += ms; ++t.calls; t.items += p.items;
+			free_events.push_back(p.a); free_events.push_back(p.b);
+		}
+		pending.clear();
+	}
+	std::map<std::string, KernelTimer> &timers() { resolve_timers(); return tm; }
+	void timers_reset(bool enable) { resolve_timers(); tm.clear(); timing = enable; }
 
 	template <class F> void launch(const char *nm, int n, const F &f)
 	{

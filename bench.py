@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- paired reads/s through the MI355X hot path (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the whole per-pair path (seed -> locate -> chain -> extend -> rescue -> CIGAR, i.e. what the
+reference does in GetChains + GetAlignments per barcode) over the workload of BASELINE.json configs[1]:
+a chr20-sized synthetic genome (64,444,167 bp) and 1,000 barcodes x 1,000 pairs of 2x150 bp haplotagging-style reads.
+Reads are uploaded to HBM before the timed region; results stay in HBM (PCIe-inclusive numbers: DESIGN.md).
+
+N > 1 (launched by torch.distributed.run): barcode groups are independent, so every rank aligns its own barcodes on
+its own replica of the index with no data-path collective (weak scaling: each rank gets a full configs[1] read set
+with its own seed); torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CHR20_LEN = 64_444_167
+SEED0 = 20250905 + 2             # seed = 20250905 + config#
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def prepare_index(cache, genome_len, rank, barrier):
+    """Synthetic genome + index (built by the product's own `bwa index` equivalent), cached under /tmp."""
+    from arachne_amd import api, synth
+    prefix = os.path.join(cache, f"g{genome_len}.fa")
+    done = prefix + ".done"
+    if rank == 0 and not os.path.exists(done):
+        os.makedirs(cache, exist_ok=True)
+        t = time.time()
+        # chr20-like: one big contig plus two small ones so that contig clamping is exercised
+        lens = [genome_len - 2_000_000, 1_500_000, 500_000] if genome_len > 8_000_000 else [genome_len]
+        g = synth.make_genome(SEED0, lens)
+        g.write_fasta(prefix)
+        log(f"genome {genome_len} bp written in {time.time() - t:.1f}s")
+        t = time.time()
+        api.index_build(prefix, prefix)
+        log(f"index built in {time.time() - t:.1f}s")
+        np.save(prefix + ".lens.npy", np.array(lens, dtype=np.int64))
+        open(done, "w").write("ok")
+    barrier()
+    return prefix
+
+
+def load_genome(prefix):
+    """Re-read the cached FASTA into the synth.Genome shape make_reads() needs."""
+    from arachne_amd import synth
+    lens = np.load(prefix + ".lens.npy")
+    raw = np.fromfile(prefix, dtype=np.uint8)
+    seqs, names, pos = [], [], 0
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate(b"ACGTN"):
+        lut[c] = i
+    for k, L in enumerate(lens):
+        nl = raw[pos:].tobytes().index(b"\n")
+        names.append(raw[pos + 1:pos + nl].tobytes().decode())
+        pos += nl + 1
+        nlines = (int(L) + 79) // 80
+        body = raw[pos:pos + int(L) + nlines]
+        s = lut[body]
+        seqs.append(s[s != 255])
+        assert len(seqs[-1]) == L, (len(seqs[-1]), L)
+        pos += int(L) + nlines
+    return synth.Genome(names, seqs, [False] * len(seqs))
+
+
+def cpu_baseline(prefix, rs, n_sample, cores):
+    """Reference C core (oracle/_ref, kind "reference") if the prebuilt .so travelled, else our CPU restatement ("port")."""
+    import refdrv
+    n = min(n_sample, rs.n_pairs)
+    seqs, lens = rs.seqs[:2 * n], rs.lens[:2 * n]
+    if refdrv.available():
+        r = refdrv.Ref(prefix)
+        kind = "reference"
+    else:
+        import subprocess
+        import oradrv
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        r = oradrv.Oracle(prefix)
+        kind = "port"
+    out = r.batch(seqs, lens, n_threads=cores)
+    secs = out["secs"]
+    return dict(value=n / secs, unit="pairs/s", cores=cores, kind=kind,
+                sample=f"first {n} pairs of the same read set, candidate generation + rescue + CIGAR for every candidate "
+                       f"(gobwa.go:226-337,400-415 call sequence), {cores} OpenMP threads, {secs:.1f}s"), out
+
+
+def algorithmic_bytes(prefix, rs, n_sample):
+    """per-read algorithmic bytes of seeding, counted by the instrumented CPU restatement."""
+    import subprocess
+    import oradrv
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    o = oradrv.Oracle(prefix)
+    n = min(n_sample, rs.n_pairs)
+    o.counters(reset=True)
+    o.batch(rs.seqs[:2 * n], rs.lens[:2 * n], n_threads=os.cpu_count() or 1)
+    c = o.counters()
+    reads = 2 * n
+    L = float(np.mean(rs.lens[:2 * n]))
+    per_read_seed = 64.0 * (c["ext_same_block"] + 2 * c["ext_two_block"]) / reads + L / 4
+    per_read_locate = (64.0 * c["sa_lf_steps"] + 8.0 * c["sa_lookups"]) / reads
+    return dict(seed=per_read_seed, locate=per_read_locate, counters={k: v / reads for k, v in c.items() if k != "n_reads"})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--barcodes", type=int, default=1000)
+    ap.add_argument("--pairs-per-barcode", type=int, default=1000)
+    ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
+    ap.add_argument("--chunk-pairs", type=int, default=125_000, help="pairs per device batch inside one step")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default="/tmp/arx_bench_cache")
+    ap.add_argument("--lib", default=None, help="(dry runs of this script only) alternative library exporting the C ABI")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def barrier():
+            pass
+
+    from arachne_amd import api, synth
+    prefix = prepare_index(args.cache, args.genome_len, rank, barrier)
+    genome = load_genome(prefix)
+    t = time.time()
+    rs = synth.make_reads(SEED0 + 1000 * rank, genome, args.barcodes, args.pairs_per_barcode)
+    log(f"rank {rank}: {rs.n_pairs} pairs synthesised in {time.time() - t:.1f}s")
+
+    if args.lib:
+        api.LIB_PATH = args.lib
+        ref = api.Reference(prefix, local_rank, lib_path=args.lib)
+    else:
+        ref = api.load_reference(prefix, device=local_rank)
+        assert ref.backend == "hip:gfx950", ref.backend
+    # whole barcodes per device batch; reads go to HBM before the clock starts
+    po = rs.pair_offsets()
+    batches, start = [], 0
+    while start < len(po) - 1:
+        end = start + 1
+        while end < len(po) - 1 and po[end + 1] - po[start] <= args.chunk_pairs:
+            end += 1
+        p0, p1 = int(po[start]), int(po[end])
+        batches.append(ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1]))
+        start = end
+    log(f"rank {rank}: {len(batches)} device batches uploaded")
+
+    def step():
+        for b in batches:
+            b.run(api.STAGE_ALN)
+
+    for _ in range(args.warmup):
+        step()
+    ref.kernel_times_reset(True)   # HIP events around every launch on the launch stream, resolved after the timed region
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.time() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ktimes = ref.kernel_times()
+    counts = [b.counts() for b in batches]
+
+    if rank == 0:
+        pairs_per_step = rs.n_pairs * world
+        value = pairs_per_step * args.steps / dt
+        out = dict(metric="paired reads/sec through the per-barcode alignment path (seed+extend+rescue+CIGAR), GRCh38 chr20-size, 2x150bp",
+                   value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1000.0 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="u8/i16/i32 integer (max-plus DP) + u64 (FM-index)", data="synthetic",
+                   config=dict(workload="BASELINE.json configs[1]: GRCh38 chr20-size genome (%d bp synthetic, planted repeats), "
+                                        "%d barcodes x %d pairs 2x150bp per GPU" % (args.genome_len, args.barcodes, args.pairs_per_barcode),
+                               pairs_per_step_per_gpu=rs.n_pairs, device_batches=len(batches), parallelism=f"barcode-sharded x{world}"))
+        # roofline of the seeding kernel (the HBM-bound headline)
+        try:
+            ab = algorithmic_bytes(prefix, rs, 10_000)
+            reads_per_launch = 2.0 * rs.n_pairs / len(batches)
+            k = ktimes.get("seed")
+            if k and k["calls"]:
+                avg_ms = k["ms"] / k["calls"]
+                achieved = ab["seed"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
+                out["roofline"] = dict(kernel="seed (KSeed: SMEM search, bwt_extend/bwt_2occ4)", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
+                                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                                       algorithmic_bytes_per_read=ab["seed"], reads_per_launch=reads_per_launch, avg_launch_ms=avg_ms)
+            kl = ktimes.get("locate")
+            if kl and kl["calls"]:
+                avg_ms = kl["ms"] / kl["calls"]
+                ach = ab["locate"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
+                out["roofline_locate"] = dict(kernel="locate (KLocate: bwt_sa LF walk)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                                              frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms)
+            out["work_per_read"] = ab["counters"]
+        except Exception as e:  # the roofline needs the oracle library; never fail the throughput line over it
+            log("roofline skipped:", repr(e))
+        tot = sum(v["ms"] for v in ktimes.values()) or 1.0
+        out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernel_share"] = {k: round(v["ms"] / tot, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])}
+        out["rounds"] = dict(ext=max(c["ext_rounds"] for c in counts), rescue=max(c["rescue_rounds"] for c in counts),
+                             ext_dp_per_pair=sum(c["n_ext"] for c in counts) / rs.n_pairs, sw_per_pair=sum(c["n_sw"] for c in counts) / rs.n_pairs,
+                             regs_per_read=sum(c["n_regs"] for c in counts) / (2.0 * rs.n_pairs))
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cores = os.cpu_count() or 1
+                n_sample = args.cpu_sample or min(rs.n_pairs, 4000 * cores)
+                cb, ref_out = cpu_baseline(prefix, rs, n_sample, cores)
+                out["cpu_baseline"] = cb
+                # the same sample through the GPU path must agree with the CPU path it is timed beside
+                import parity
+                n = min(n_sample, 2000)
+                dev = ref.mem_mate_sw(rs.seqs[:2 * n], rs.lens[:2 * n])
+                sub = refdrv_slice(ref_out, 2 * n)
+                parity.check_final(dev, sub)
+                out["parity_checked_pairs"] = n
+            except Exception as e:
+                log("cpu baseline skipped:", repr(e))
+        print(json.dumps(out), flush=True)
+    for b in batches:
+        b.free()
+    ref.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def refdrv_slice(out, n_reads):
+    """First n_reads reads of a refdrv/oradrv batch() result."""
+    off = out["reg_off"][:n_reads + 1]
+    nreg = int(off[-1])
+    alns = out["alns"][:nreg]
+    ncig = int(alns[-1, 8] + alns[-1, 7]) if nreg else 0
+    return dict(reg_off=off, regs=out["regs"][:nreg], alns=alns, cigars=out["cigars"][:ncig])
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,10 @@ typedef struct {
 typedef struct { int64_t pos; int32_t rid, n, seed_off, w, kept, first, is_alt, head, tail; float frac_rep; } arx_chain; /* mem_chain_t */
 typedef struct { int64_t rbeg; int32_t qbeg, len; } arx_seed;                                                         /* mem_seed_t  */
 
+/* Builds <prefix>.{bwt,sa,pac,ann,amb} from a plain-text FASTA, byte-identical to the reference's `bwa index`
+ * (bwa/bwtindex.c:251-316 bwa_idx_build); host-side, needs no GPU.  msg (may be NULL) receives the error text. */
+int arx_index_build(const char *fasta, const char *prefix, char *msg, int32_t msg_cap);
+
 /* Loads <prefix>.{bwt,sa,pac,ann,amb,alt} (files written by `bwa index`) into HBM of `device`. */
 int arx_open(const char *prefix, int device, arx_ctx **out);
 void arx_close(arx_ctx *ctx);
