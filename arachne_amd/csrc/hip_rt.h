@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <cstdlib>
+#include "hip_sw_coop.h"
 
 namespace arx {
 
@@ -131,6 +133,18 @@ struct HipRT {
 		Scope sc(*this, nm, n);
 		int blocks = (n + 63) / 64; if (blocks > n_cu) blocks = n_cu;
 		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	// rescue SW: 16 lanes per alignment (hip_sw_coop.h); ARX_SW_SIMPLE=1 selects the one-thread-per-alignment kernel for A/B runs
+	bool sw_simple = getenv("ARX_SW_SIMPLE") != nullptr;
+	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); return; }
+		Scope sc(*this, nm, n);
+		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
+		if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
+		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words_per_thread)

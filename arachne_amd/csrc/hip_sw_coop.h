@@ -1,0 +1,183 @@
+// hip_sw_coop.h -- wavefront-cooperative Smith-Waterman kernels for gfx950 (HIP only).
+//
+// sw_u8_g16: the rescue SW (ksw_align2/ksw_u8, ksw.c:111-230,343-365).  The SSE2 original keeps 16 query stripes in the
+// 16 byte lanes of an XMM register; here the 16 stripes live in 16 adjacent GPU lanes (one DPP row), four alignments
+// per 64-wide wavefront.  H/E/Hmax stay in VGPRs (slen <= SL values per lane, loops fully unrolled), the byte shift of
+// `_mm_slli_si128(x, 1)` is a lane shift inside the row, `_mm_movemask_epi8` is a ballot, the horizontal max a 4-step
+// butterfly.  Cell order, saturation, lazy-F early exit and tie rules are those of the reference, so the results are
+// bit-identical to u8_align() in dev_sw.h (the one-thread-per-alignment form the parity tests pin).
+#pragma once
+#include "arx_dev.h"
+#include "dev_sw.h"
+#include "dev_regs.h"
+
+namespace arx {
+
+__device__ __forceinline__ int g16_shift_up(int v, int l) // lane l of each 16-lane row receives lane l-1's value, lane 0 receives 0
+{
+	int r = __shfl_up(v, 1, 16);
+	return l == 0 ? 0 : r;
+}
+__device__ __forceinline__ int g16_max(int v)
+{
+#pragma unroll
+	for (int o = 8; o; o >>= 1) { int t = __shfl_xor(v, o, 16); v = v > t ? v : t; }
+	return v;
+}
+__device__ __forceinline__ int g16_min(int v)
+{
+#pragma unroll
+	for (int o = 8; o; o >>= 1) { int t = __shfl_xor(v, o, 16); v = v < t ? v : t; }
+	return v;
+}
+__device__ __forceinline__ bool g16_all(bool p)
+{
+	unsigned long long m = __ballot(p);
+	return ((m >> (__lane_id() & 48)) & 0xffffull) == 0xffffull;
+}
+
+// per-row score lookup: nibble q of the word is S(tb, q) + shift for q = 0..3 (bases), 4 (N) and 5 (stripe padding)
+__device__ __forceinline__ uint32_t u8_score_word(int tb)
+{
+	// match 1+4 = 5, mismatch -4+4 = 0, N -1+4 = 3, padding 0+4 = 4
+	if (tb > 3) return 0x433333u;
+	return 0x430000u | (5u << (4 * tb));
+}
+
+struct SwSeqs { // how the two passes read their sequences without materialising them
+	const uint8_t *mate; int l_ms;   // forward mate; the query is its reverse complement (bwamem_pair.c:134-137)
+	int64_t rb;                      // doubled coordinate of target[0]
+	int q_rev, t_rev;                // second pass: the first q_rev / t_rev elements are read back to front (ksw.c:357)
+	__device__ __forceinline__ int q0(int k) const { int b = mate[l_ms - 1 - k]; return b < 4 ? 3 - b : 4; }
+	__device__ __forceinline__ int q(int k) const { return q0(k < q_rev ? q_rev - 1 - k : k); }
+	__device__ __forceinline__ int t(const IndexView &ix, int i) const { return ref_base(ix, rb + (i < t_rev ? t_rev - 1 - i : i)); }
+};
+
+// one ksw_u8 pass by a 16-lane group; every lane returns the same U8Res (score2/te2 only valid in lane 0 of the group)
+template <int SL>
+__device__ U8Res sw_u8_pass_g16(const IndexView &ix, const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
+{
+	const int l = __lane_id() & 15;
+	const int slen = (qlen + 15) >> 4;
+	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000, endsc = (xtra & KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
+	int H0[SL], H1[SL], E[SL], HM[SL], Q4[SL];
+#pragma unroll
+	for (int j = 0; j < SL; ++j) {
+		const int k = j + l * slen;
+		H0[j] = H1[j] = E[j] = HM[j] = 0;
+		Q4[j] = 4 * ((j < slen && k < qlen) ? sq.q(k) : 5);
+	}
+	int gmax = 0, te = -1, hlast = 0, rows = 0;
+	for (int i = 0; i < tlen; ++i) {
+		const uint32_t W = u8_score_word(sq.t(ix, i));
+		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
+#pragma unroll
+		for (int j = 0; j < SL; ++j) {
+			if (j < slen) {
+				int s = (int)((W >> Q4[j]) & 15u);
+				int t = h + s; t = t < 255 ? t : 255;      // _mm_adds_epu8
+				int hh = t - 4; hh = hh > 0 ? hh : 0;      // _mm_subs_epu8(h, shift)
+				hh = hh > E[j] ? hh : E[j];
+				hh = hh > f ? hh : f;
+				mx = mx > hh ? mx : hh;
+				H1[j] = hh;
+				int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;     // subs(h, oe): o+e = 7 for both gap kinds
+				int e1 = E[j] - 1; e1 = e1 > 0 ? e1 : 0;
+				E[j] = e1 > t7 ? e1 : t7;
+				int f1 = f - 1; f1 = f1 > 0 ? f1 : 0;
+				f = f1 > t7 ? f1 : t7;
+				h = H0[j];
+			}
+		}
+		// lazy-F (ksw.c:177-189)
+		{
+			bool stop = false;
+			for (int k2 = 0; k2 < 16 && !stop; ++k2) {
+				f = g16_shift_up(f, l);
+#pragma unroll
+				for (int j = 0; j < SL; ++j) {
+					if (j < slen && !stop) {
+						int hh = H1[j] > f ? H1[j] : f;
+						H1[j] = hh;
+						int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;
+						f = f - 1; f = f > 0 ? f : 0;
+						if (g16_all(!(f > t7))) stop = true;
+					}
+				}
+			}
+		}
+		const int imax = g16_max(mx);
+		if (minsc < 0x10000 && l == 0) rowmax[i] = (uint8_t)imax;
+		++rows;
+		bool brk = false;
+		if (imax > gmax) {
+			gmax = imax; te = i;
+#pragma unroll
+			for (int j = 0; j < SL; ++j) HM[j] = H1[j];
+			if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
+		}
+		if (brk) break;
+#pragma unroll
+		for (int j = 0; j < SL; ++j) { H0[j] = H1[j]; if (j == slen - 1) hlast = H1[j]; }
+	}
+	U8Res r;
+	r.score = gmax + 4 < 255 ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
+	if (r.score != 255) {
+		int bv = -1, bq = 0x7fffffff; // this lane's best saved value and the smallest query position holding it
+#pragma unroll
+		for (int j = 0; j < SL; ++j) {
+			if (j < slen) {
+				int v = HM[j], qp = j + l * slen;
+				if (v > bv) { bv = v; bq = qp; }
+			}
+		}
+		const int vmax = g16_max(bv);
+		r.qe = g16_min(bv == vmax ? bq : 0x7fffffff);
+		if (minsc < 0x10000 && l == 0) { // replay of the b[] list (ksw.c:192-200,218-226), see u8_pass() in dev_sw.h
+			const int d = r.score, low = te - d, high = te + d; // (score + max - 1) / max with max = 1
+			int bi = -1, bs = -1;
+			for (int i = 0; i < rows; ++i) {
+				int im = rowmax[i];
+				if (im < minsc) continue;
+				if (bi < 0 || bi + 1 != i) {
+					if (bi >= 0 && (bi < low || bi > high) && bs > r.score2) { r.score2 = bs; r.te2 = bi; }
+					bi = i; bs = im;
+				} else if (bs < im) { bi = i; bs = im; }
+			}
+			if (bi >= 0 && (bi < low || bi > high) && bs > r.score2) { r.score2 = bs; r.te2 = bi; }
+		}
+	}
+	return r;
+}
+
+// one rescue alignment per 16-lane group: forward pass, then the pass over the reversed prefixes (ksw.c:343-365)
+template <int SL>
+__device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_ms, int64_t rb, int tlen, uint8_t *rowmax, U8Res *out)
+{
+	const int xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
+	SwSeqs sq{mate, l_ms, rb, 0, 0};
+	U8Res r = sw_u8_pass_g16<SL>(ix, sq, l_ms, tlen, xtra, rowmax);
+	if (!(r.score < (xtra & 0xffff))) {
+		SwSeqs s2{mate, l_ms, rb, r.qe + 1, r.te + 1};
+		U8Res rr = sw_u8_pass_g16<SL>(ix, s2, r.qe + 1, tlen, KSW_XSTOP | r.score, rowmax);
+		if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+	}
+	if ((__lane_id() & 15) == 0) *out = r;
+}
+
+constexpr int SW_T_CAP = 1088; // >= PES_HIGH - PES_LOW + 2 * MAX_READ_LEN, multiple of 64
+
+template <int SL>
+__global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
+                                                  const SwTask *tasks, U8Res *res, int n)
+{
+	__shared__ uint8_t rowmax_lds[4][SW_T_CAP];
+	const int g = threadIdx.x >> 4;
+	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
+		const SwTask t = tasks[i];
+		const int r = 2 * t.pair + t.o;
+		sw_u8_align_g16<SL>(ix, bases + base_off[r], lens[r], t.rb, (int)(t.re - t.rb), rowmax_lds[g], &res[t.pair]);
+	}
+}
+
+} // namespace arx

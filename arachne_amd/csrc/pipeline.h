@@ -346,7 +346,7 @@ public:
 			if (round > 2 * MAX_RESCUE + 4) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; }
 			out.n_sw_tasks += nt; ++out.rescue_rounds;
 			KSwU8 kw{ix, b.bases, b.base_off, b.lens, w.stask, w.sres, w.sw_scr, q_cap, t_cap};
-			rt.launch_rows("sw_u8", nt, kw, 16 * ((b.max_len + 15) / 16));
+			rt.run_sw_u8("sw_u8", nt, kw, b.max_len);
 		}
 	}
 
