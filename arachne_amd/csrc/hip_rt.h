@@ -147,6 +147,17 @@ struct HipRT {
 		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
+	// banded extension: 16 lanes per extension (hip_sw_coop.h)
+	template <class F> void run_extend(const char *nm, int n, const F &f, int max_len)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch_rows(nm, n, f, max_len + 1); return; }
+		Scope sc(*this, nm, n);
+		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
+		if (max_len <= 159) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, f.res, n);
+		else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, f.res, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words_per_thread)
 	{
 		if (n <= 0) return;

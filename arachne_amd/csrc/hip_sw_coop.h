@@ -180,4 +180,152 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// ext2_g16: banded extension (ksw_extend2, ksw.c:380-479) by a 16-lane group, four extensions per wavefront.
+// Column j of the reference's eh[] array lives in lane j / Cw, register j % Cw.  Within a row, M(i,j) only depends on the
+// previous row, and both gap states are fed from M (not H), so the row is evaluated in three sweeps instead of a serial
+// chain: (1) M and the insertion seeds t(j) = max(M(j) - 7, 0); (2) F(j) = max_{beg<=k<j} (t(k) + k) - (j - 1), a prefix
+// maximum done per lane and then across the 16 lanes with a 4-step scan (the max-plus form of the serial
+// f = max(f - 1, t) chain, exact because every t is >= 0); (3) H, E, the row maximum with the reference's tie rule
+// (largest column wins) and the adaptive band, the latter two as group reductions.  Columns outside [beg, end] keep
+// their stale values exactly as the reference's array does, which is what makes the shrinking/growing band bit-exact.
+// ------------------------------------------------------------------------------------------------------------------
+template <int C>
+__device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtTask &t)
+{
+	const int l = __lane_id() & 15;
+	const int qlen = t.qlen, tlen = t.tlen, h0 = t.h0;
+	const int Cw = (qlen + 16) >> 4; // ceil((qlen + 1) / 16) columns per lane
+	const int c0 = l * Cw;
+	const int NEG = -0x40000000;
+	int H[C], E[C], Q[C], Mv[C], hv[C], pref[C];
+#pragma unroll
+	for (int u = 0; u < C; ++u) {
+		const int j = c0 + u;
+		int v = j == 0 ? h0 : h0 - 6 - j; // first row (ksw.c:395-397): h0, h0-7, then minus one per column while positive
+		H[u] = v > 0 ? v : 0;
+		E[u] = 0;
+		Q[u] = (u < Cw && j < qlen) ? bases[t.qoff + j * t.qdir] : 4;
+	}
+	int w = t.w;
+	{
+		int mg = qlen + OPT_PEN_CLIP5 - 5; // max_ins == max_del (ksw.c:402-407)
+		mg = mg > 1 ? mg : 1;
+		w = w < mg ? w : mg;
+	}
+	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = ref_base(ix, t.tpos + (int64_t)i * t.tdir);
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1init = 0;
+		if (beg == 0) { h1init = h0 - (OPT_O_DEL + OPT_E_DEL * (i + 1)); if (h1init < 0) h1init = 0; }
+		// sweep 1: M, and the running maximum of t(k) + k inside the lane
+		int pm = NEG;
+#pragma unroll
+		for (int u = 0; u < C; ++u) {
+			const int j = c0 + u;
+			const bool act = u < Cw && j >= beg && j < end;
+			int M = act && H[u] ? H[u] + sc_mat(tb, Q[u]) : 0;
+			Mv[u] = M;
+			int tv = M - 7; tv = tv > 0 ? tv : 0;
+			pref[u] = pm;
+			if (act) { int key = tv + j; pm = pm > key ? pm : key; }
+		}
+		// exclusive prefix maximum of the lane maxima across the group
+		int x = pm;
+#pragma unroll
+		for (int o = 1; o < 16; o <<= 1) { int y = __shfl_up(x, o, 16); if (l >= o) x = x > y ? x : y; }
+		int ex = __shfl_up(x, 1, 16);
+		if (l == 0) ex = NEG;
+		// sweep 2: F, H, E and the lane's row maximum (largest column wins ties, ksw.c:437)
+		int m_loc = -1, mj_loc = -1;
+#pragma unroll
+		for (int u = 0; u < C; ++u) {
+			const int j = c0 + u;
+			const bool act = u < Cw && j >= beg && j < end;
+			if (act) {
+				int pmx = ex > pref[u] ? ex : pref[u];
+				int F = j == beg ? 0 : pmx - (j - 1);
+				int h = Mv[u] > E[u] ? Mv[u] : E[u];
+				h = h > F ? h : F;
+				hv[u] = h;
+				int e = E[u] - 1, tt = Mv[u] - 7;
+				e = e > tt ? e : tt;
+				E[u] = e > 0 ? e : 0;
+				if (h >= m_loc) { m_loc = h; mj_loc = j; }
+			} else hv[u] = 0;
+		}
+		// sweep 3: eh[j].h <- H(i, j-1): shift by one column, across the lane boundary by one lane
+		int last_h = 0;
+#pragma unroll
+		for (int u = 0; u < C; ++u) if (u == Cw - 1) last_h = hv[u];
+		const int from_prev = __shfl_up(last_h, 1, 16);
+#pragma unroll
+		for (int u = C - 1; u >= 0; --u) {
+			const int j = c0 + u;
+			if (u < Cw && j <= qlen) {
+				if (j > beg && j <= end) H[u] = u == 0 ? from_prev : hv[u - 1];
+				else if (j == beg) H[u] = h1init;
+				if (j == end) { E[u] = 0; if (j == beg) H[u] = h1init; }
+			}
+		}
+		// row maximum and its column; the value entering column `end`
+		int packed = g16_max(m_loc < 0 ? -1 : (m_loc << 12) | mj_loc); // mj_loc < 4096
+		int m = packed < 0 ? 0 : packed >> 12, mj = packed < 0 ? -1 : packed & 0xfff;
+		if (end == qlen) {
+			int own = -1;
+#pragma unroll
+			for (int u = 0; u < C; ++u) if (u < Cw && c0 + u == end - 1 && end - 1 >= beg) own = hv[u];
+			int h1 = g16_max(own);
+			if (h1 < 0) h1 = h1init; // empty row: h1 keeps its initial value
+			max_ie = gscore > h1 ? max_ie : i;
+			gscore = gscore > h1 ? gscore : h1;
+		}
+		if (m == 0) break;
+		if (m > max) {
+			max = m; max_i = i; max_j = mj;
+			int off = mj - i; off = off < 0 ? -off : off;
+			max_off = max_off > off ? max_off : off;
+		} else {
+			if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * OPT_E_DEL > OPT_ZDROP) break; }
+			else { if (max - m - ((mj - max_j) - (i - max_i)) * OPT_E_INS > OPT_ZDROP) break; }
+		}
+		// adaptive band (ksw.c:466-469) on the freshly written row
+		int first = 0x7fffffff;
+#pragma unroll
+		for (int u = C - 1; u >= 0; --u) {
+			const int j = c0 + u;
+			if (u < Cw && j >= beg && j < end && (H[u] != 0 || E[u] != 0)) first = j;
+		}
+		first = g16_min(first);
+		const int nbeg = first < end ? first : end;
+		int last = -1;
+#pragma unroll
+		for (int u = 0; u < C; ++u) {
+			const int j = c0 + u;
+			if (u < Cw && j >= nbeg && j <= end && j <= qlen && (H[u] != 0 || E[u] != 0)) last = j;
+		}
+		last = g16_max(last);
+		if (last < nbeg) last = nbeg - 1;
+		beg = nbeg;
+		end = last + 2 < qlen ? last + 2 : qlen;
+	}
+	ExtRes r;
+	r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	return r;
+}
+
+template <int C>
+__global__ void __launch_bounds__(64) k_extend_g16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
+{
+	const int g = threadIdx.x >> 4;
+	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
+		const ExtTask t = tasks[i];
+		ExtRes r = ext2_g16<C>(ix, bases, t);
+		if ((threadIdx.x & 15) == 0) res[t.owner] = r;
+	}
+}
+
 } // namespace arx

@@ -313,7 +313,7 @@ public:
 			if (round > w.T + R + 8) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; } // cannot happen: every round retires a DP
 			out.n_ext_tasks += nt; ++out.ext_rounds;
 			KExtend ke{ix, b.bases, w.etask, w.eres};
-			rt.launch_rows("extend", nt, ke, b.max_len + 1);
+			rt.run_extend("extend", nt, ke, b.max_len);
 			if (trace) { rt.sync(); fprintf(stderr, "[arx]   extend kernel done\n"); fflush(stderr); }
 		}
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
@@ -353,7 +353,7 @@ public:
 	// ---- stage 6: CIGAR for every region; retried with wider CIGAR slots if one overflows
 	int stage_reg2aln(const DeviceBatch &b, Work &w)
 	{
-		const int slots = rt.max_slots_small();
+		const int slots = rt.max_slots();
 		const int eh_words = 2 * (b.max_len + 2);
 		const int z_cap = b.max_len * (2 * b.max_len + 64);
 		const size_t P = (size_t)w.P + 1;
@@ -364,7 +364,7 @@ public:
 			if (w.cig) rt.free(w.cig);
 			w.cig = rt.template alloc<uint32_t>(P * w.cig_w);
 			KReg2Aln k{ix, b.bases, b.base_off, b.lens, w.preg_off, w.n_regs, b.n_reads, w.pregs, w.alns, w.cig, w.cig_w, w.eh, eh_words, w.z, z_cap, w.err};
-			rt.launch_small("reg2aln", (int)w.P, k);
+			rt.launch("reg2aln", (int)w.P, k);
 			uint32_t e = read_err(w);
 			if (!(e & ERR_CIGAR_OVERFLOW)) return (int)e;
 			if (w.cig_w >= 1024) return (int)e;
