@@ -1,8 +1,14 @@
 // api_impl.h -- implementation of the C-ABI declared in include/arachne_amd.h on top of Pipeline<RT>.
 // The product build (arx_api.hip) instantiates it with HipRT.
+//
+// Concurrency: a context owns the index in HBM; every batch owns its own runtime (HIP stream, scan scratch, event
+// timers), so several host threads can drive several batches at once and their kernels overlap on the device -- the
+// step/DP round trips of one batch hide behind the kernels of the others.
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include "../../include/arachne_amd.h"
 #include "index_io.h"
@@ -11,17 +17,27 @@
 
 namespace arx {
 
+template <class RT> struct Batch;
+
 template <class RT> struct Context {
-	RT rt;
+	RT rt;                      // index uploads
+	int device = 0;
 	HostIndex hix;
 	IndexView ix;
 	std::vector<void *> dev_index;
-	std::string last_error;
 	std::vector<const char *> name_ptrs;
+	std::mutex mu;
+	std::string last_error;
+	std::set<Batch<RT> *> live;
+	std::map<std::string, KernelTimer> tm_done; // timers of batches already freed
+	bool timing = false;
 
-	std::string open(const std::string &prefix, int device)
+	void set_error(const std::string &e) { std::lock_guard<std::mutex> g(mu); last_error = e; }
+
+	std::string open(const std::string &prefix, int dev)
 	{
-		std::string e = rt.init(device);
+		device = dev;
+		std::string e = rt.init(dev);
 		if (!e.empty()) return e;
 		e = load_index(prefix, hix);
 		if (!e.empty()) return e;
@@ -43,16 +59,34 @@ template <class RT> struct Context {
 
 template <class RT> struct Batch {
 	Context<RT> *ctx;
+	RT rt;                      // this batch's stream
 	Pipeline<RT> pipe;
 	typename Pipeline<RT>::DeviceBatch db;
 	typename Pipeline<RT>::Work work;
 	BatchResult res;
 	bool downloaded = false;
-	Batch(Context<RT> *c) : ctx(c), pipe(c->rt, c->ix) {}
-	~Batch() { pipe.free_work(work); pipe.release(db); }
+	int done_stage = 0;
+	explicit Batch(Context<RT> *c) : ctx(c), pipe(rt, c->ix)
+	{
+		std::string e = rt.init(c->device);
+		if (!e.empty()) throw std::runtime_error(e);
+		std::lock_guard<std::mutex> g(c->mu);
+		c->live.insert(this);
+	}
+	~Batch()
+	{
+		rt.bind();
+		pipe.free_work(work); pipe.release(db);
+		std::lock_guard<std::mutex> g(ctx->mu);
+		for (auto &kv : rt.timers()) { KernelTimer &t = ctx->tm_done[kv.first]; t.ms += kv.second.ms; t.calls += kv.second.calls; t.items += kv.second.items; }
+		ctx->live.erase(this);
+	}
 };
 
 } // namespace arx
+
+// every entry converts C++ exceptions (HIP errors, bad_alloc) into an error code: the library never aborts the caller
+#define ARX_TRY(ctxp, ...) try { __VA_ARGS__ } catch (const std::exception &ex_) { if (ctxp) (ctxp)->set_error(ex_.what()); return ARX_E_DEVICE; }
 
 #define ARX_DEFINE_C_API(RT)                                                                                                        \
 	using Ctx = arx::Context<RT>;                                                                                                   \
@@ -69,14 +103,22 @@ template <class RT> struct Batch {
 	int arx_open(const char *prefix, int device, arx_ctx **out)                                                                     \
 	{                                                                                                                               \
 		*out = 0;                                                                                                                   \
-		Ctx *c = new Ctx();                                                                                                         \
-		std::string e = c->open(prefix, device);                                                                                    \
+		Ctx *c = 0;                                                                                                                 \
+		std::string e;                                                                                                              \
+		try { c = new Ctx(); e = c->open(prefix, device); } catch (const std::exception &ex) { e = ex.what(); }                     \
 		if (!e.empty()) { g_open_error = e; delete c; return ARX_E_OPEN; }                                                          \
 		*out = (arx_ctx *)c;                                                                                                        \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	void arx_close(arx_ctx *h) { delete (Ctx *)h; }                                                                                 \
-	const char *arx_last_error(arx_ctx *h) { return h ? ((Ctx *)h)->last_error.c_str() : g_open_error.c_str(); }                    \
+	const char *arx_last_error(arx_ctx *h)                                                                                          \
+	{                                                                                                                               \
+		if (!h) return g_open_error.c_str();                                                                                        \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		std::lock_guard<std::mutex> g(c->mu);                                                                                       \
+		g_open_error = c->last_error;                                                                                               \
+		return g_open_error.c_str();                                                                                                \
+	}                                                                                                                               \
 	const char *arx_backend(void) { return RT::name(); }                                                                            \
 	int arx_contigs(arx_ctx *h, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens,               \
 	                const int32_t **is_alt, int64_t *l_pac)                                                                         \
@@ -90,42 +132,52 @@ template <class RT> struct Batch {
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h;                                                                                                          \
 		*out = 0;                                                                                                                   \
-		if (n_reads <= 0 || (n_reads & 1)) { c->last_error = "n_reads must be positive and even (read 2i/2i+1 are mates)"; return ARX_E_ARG; } \
+		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
 		for (int i = 0; i < n_reads; ++i)                                                                                           \
-			if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->last_error = "read length outside [0, 249]"; return ARX_E_ARG; }   \
-		Bat *b = new Bat(c);                                                                                                        \
-		b->db = b->pipe.upload(bases, lens, n_reads);                                                                               \
-		*out = (arx_batch *)b;                                                                                                      \
+			if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; }     \
+		ARX_TRY(c, Bat *b = new Bat(c); b->rt.bind(); b->db = b->pipe.upload(bases, lens, n_reads); *out = (arx_batch *)b;)         \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_run(arx_ctx *h, arx_batch *bh, int32_t last_stage)                                                                \
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
-		b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->downloaded = false;                                             \
-		int rc = b->pipe.stage_seed(b->db, b->work);                                                                                \
-		if (rc == -2) { c->last_error = "batch too large: seed occurrences exceed 2^30, split the batch"; return ARX_E_TOO_LARGE; } \
-		b->res.n_occ = b->work.T;                                                                                                   \
-		if (last_stage >= ARX_STAGE_CHAIN) b->pipe.stage_chain(b->db, b->work);                                                     \
-		if (last_stage >= ARX_STAGE_EXTEND) b->pipe.stage_extend(b->db, b->work, b->res);                                           \
-		if (last_stage >= ARX_STAGE_RESCUE) b->pipe.stage_rescue(b->db, b->work, b->res);                                           \
-		uint32_t e = last_stage >= ARX_STAGE_ALN ? (uint32_t)b->pipe.stage_reg2aln(b->db, b->work) : b->pipe.read_err(b->work);     \
-		c->rt.sync();                                                                                                               \
-		if (e) { c->last_error = "device stage raised error bits " + std::to_string(e); return ARX_E_DEVICE; }                      \
+		ARX_TRY(c,                                                                                                                  \
+			b->rt.bind();                                                                                                           \
+			b->rt.set_timing(c->timing);                                                                                            \
+			/* stages already done are kept (run(SEED) then run(ALN) resumes); asking for a stage again restarts the batch */       \
+			if (last_stage <= b->done_stage) { b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; }        \
+			b->downloaded = false;                                                                                                  \
+			if (b->done_stage < ARX_STAGE_SEED) {                                                                                   \
+				int rc = b->pipe.stage_seed(b->db, b->work);                                                                        \
+				if (rc == -2) { c->set_error("batch too large: seed occurrences exceed 2^30, split the batch"); return ARX_E_TOO_LARGE; } \
+				b->res.n_occ = b->work.T;                                                                                           \
+			}                                                                                                                       \
+			if (b->done_stage < ARX_STAGE_CHAIN && last_stage >= ARX_STAGE_CHAIN) b->pipe.stage_chain(b->db, b->work);              \
+			if (b->done_stage < ARX_STAGE_EXTEND && last_stage >= ARX_STAGE_EXTEND) b->pipe.stage_extend(b->db, b->work, b->res);   \
+			if (b->done_stage < ARX_STAGE_RESCUE && last_stage >= ARX_STAGE_RESCUE) b->pipe.stage_rescue(b->db, b->work, b->res);   \
+			uint32_t e = last_stage >= ARX_STAGE_ALN ? (uint32_t)b->pipe.stage_reg2aln(b->db, b->work) : b->pipe.read_err(b->work); \
+			b->done_stage = last_stage;                                                                                             \
+			b->rt.sync();                                                                                                           \
+			if (e) { c->set_error("device stage raised error bits " + std::to_string(e)); return ARX_E_DEVICE; }                    \
+		)                                                                                                                           \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
-	int arx_batch_counts(arx_ctx *, arx_batch *bh, int64_t *c8)                                                                     \
+	int arx_batch_counts(arx_ctx *h, arx_batch *bh, int64_t *c8)                                                                    \
 	{                                                                                                                               \
-		Bat *b = (Bat *)bh;                                                                                                         \
-		if (b->work.alns && !b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                     \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		ARX_TRY(c,                                                                                                                  \
+			b->rt.bind();                                                                                                           \
+			if (b->work.alns && !b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                 \
+		)                                                                                                                           \
 		c8[0] = b->db.n_reads; c8[1] = (int64_t)b->res.regs.size(); c8[2] = (int64_t)b->res.cigars.size(); c8[3] = b->res.n_occ;    \
 		c8[4] = b->res.ext_rounds; c8[5] = b->res.n_ext_tasks; c8[6] = b->res.rescue_rounds; c8[7] = b->res.n_sw_tasks;             \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
-	int arx_batch_fetch(arx_ctx *, arx_batch *bh, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars)                 \
+	int arx_batch_fetch(arx_ctx *h, arx_batch *bh, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars)                \
 	{                                                                                                                               \
-		Bat *b = (Bat *)bh;                                                                                                         \
-		if (!b->work.alns) return ARX_E_ARG;                                                                                        \
-		if (!b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                                     \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.alns) { c->set_error("arx_batch_fetch before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }               \
+		ARX_TRY(c, b->rt.bind(); if (!b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; })           \
 		static_assert(sizeof(arx_reg) == sizeof(arx::Reg) && sizeof(arx_aln) == sizeof(arx::Aln), "C-ABI structs must mirror the device structs"); \
 		memcpy(reg_off, b->res.reg_off.data(), 4 * b->res.reg_off.size());                                                          \
 		memcpy(regs, b->res.regs.data(), sizeof(arx::Reg) * b->res.regs.size());                                                    \
@@ -137,8 +189,9 @@ template <class RT> struct Batch {
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (!b->work.intv) return ARX_E_ARG;                                                                                        \
-		c->rt.d2h(n_intv, b->work.n_intv, 4 * (size_t)b->db.n_reads);                                                               \
-		c->rt.d2h(intv4, b->work.intv, sizeof(arx::Biv) * (size_t)b->db.n_reads * arx::CAP_INTV);                                   \
+		ARX_TRY(c, b->rt.bind();                                                                                                    \
+			b->rt.d2h(n_intv, b->work.n_intv, 4 * (size_t)b->db.n_reads);                                                           \
+			b->rt.d2h(intv4, b->work.intv, sizeof(arx::Biv) * (size_t)b->db.n_reads * arx::CAP_INTV);)                              \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_debug_chains(arx_ctx *h, arx_batch *bh, int32_t *occ_off, int32_t *n_chain, arx_chain *chains, arx_seed *seeds)   \
@@ -146,31 +199,47 @@ template <class RT> struct Batch {
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (!b->work.cout) return ARX_E_ARG;                                                                                        \
 		static_assert(sizeof(arx_chain) == sizeof(arx::Chain) && sizeof(arx_seed) == sizeof(arx::Seed), "C-ABI structs must mirror the device structs"); \
-		c->rt.d2h(occ_off, b->work.occ_off, 4 * ((size_t)b->db.n_reads + 1));                                                       \
-		c->rt.d2h(n_chain, b->work.n_chain, 4 * (size_t)b->db.n_reads);                                                             \
-		c->rt.d2h(chains, b->work.cout, sizeof(arx::Chain) * (size_t)b->work.T);                                                    \
-		c->rt.d2h(seeds, b->work.sout, sizeof(arx::Seed) * (size_t)b->work.T);                                                      \
+		ARX_TRY(c, b->rt.bind();                                                                                                    \
+			b->rt.d2h(occ_off, b->work.occ_off, 4 * ((size_t)b->db.n_reads + 1));                                                   \
+			b->rt.d2h(n_chain, b->work.n_chain, 4 * (size_t)b->db.n_reads);                                                         \
+			b->rt.d2h(chains, b->work.cout, sizeof(arx::Chain) * (size_t)b->work.T);                                                \
+			b->rt.d2h(seeds, b->work.sout, sizeof(arx::Seed) * (size_t)b->work.T);)                                                 \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_debug_core(arx_ctx *h, arx_batch *bh, int32_t *n_core, arx_reg *regs)                                             \
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (!b->work.n_core) return ARX_E_ARG;                                                                                      \
-		c->rt.d2h(n_core, b->work.n_core, 4 * (size_t)b->db.n_reads);                                                               \
-		c->rt.d2h(regs, b->work.regs, sizeof(arx::Reg) * (size_t)b->work.T);                                                        \
+		ARX_TRY(c, b->rt.bind();                                                                                                    \
+			b->rt.d2h(n_core, b->work.n_core, 4 * (size_t)b->db.n_reads);                                                           \
+			b->rt.d2h(regs, b->work.regs, sizeof(arx::Reg) * (size_t)b->work.T);)                                                   \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
-	void arx_batch_free(arx_ctx *, arx_batch *bh) { delete (Bat *)bh; }                                                             \
+	void arx_batch_free(arx_ctx *, arx_batch *bh) { try { delete (Bat *)bh; } catch (...) {} }                                      \
 	int arx_kernel_times(arx_ctx *h, int32_t cap, char *names, int32_t name_w, double *ms, int64_t *calls, int64_t *items)          \
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h;                                                                                                          \
+		std::map<std::string, arx::KernelTimer> all;                                                                                \
+		try {                                                                                                                       \
+			std::lock_guard<std::mutex> g(c->mu);                                                                                   \
+			all = c->tm_done;                                                                                                       \
+			for (Bat *b : c->live) { b->rt.bind(); for (auto &kv : b->rt.timers()) { arx::KernelTimer &t = all[kv.first]; t.ms += kv.second.ms; t.calls += kv.second.calls; t.items += kv.second.items; } } \
+		} catch (...) { return 0; }                                                                                                 \
 		int n = 0;                                                                                                                  \
-		for (auto &kv : c->rt.timers()) {                                                                                           \
+		for (auto &kv : all) {                                                                                                      \
 			if (n >= cap) break;                                                                                                    \
 			snprintf(names + (size_t)n * name_w, name_w, "%s", kv.first.c_str());                                                   \
 			ms[n] = kv.second.ms; calls[n] = kv.second.calls; items[n] = kv.second.items; ++n;                                      \
 		}                                                                                                                           \
 		return n;                                                                                                                   \
 	}                                                                                                                               \
-	void arx_kernel_times_reset(arx_ctx *h, int32_t enable) { ((Ctx *)h)->rt.timers_reset(enable != 0); }                           \
+	void arx_kernel_times_reset(arx_ctx *h, int32_t enable)                                                                         \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		try {                                                                                                                       \
+			std::lock_guard<std::mutex> g(c->mu);                                                                                   \
+			c->tm_done.clear(); c->timing = enable != 0;                                                                            \
+			for (Bat *b : c->live) { b->rt.bind(); b->rt.timers_reset(enable != 0); }                                               \
+		} catch (...) {}                                                                                                            \
+	}                                                                                                                               \
 	}

@@ -8,6 +8,7 @@
 #include <vector>
 #include <stdexcept>
 #include <cstdlib>
+#include <cstring>
 #include "hip_sw_coop.h"
 
 namespace arx {
@@ -38,33 +39,54 @@ struct HipRT {
 	int n_cu = 256;
 	bool timing = false;
 	std::map<std::string, KernelTimer> tm;
-	void *scan_tmp = 0; size_t scan_tmp_bytes = 0; int64_t *d_total = 0;
+	void *scan_tmp = 0; size_t scan_tmp_bytes = 0; int64_t *d_total = 0; void *pinned = 0;
 
+	int dev = 0;
+	void bind() { (void)hipSetDevice(dev); }           // the current device is per host thread
+	void set_timing(bool on) { timing = on; }
 	std::string init(int device)
 	{
 		int n = 0;
+		dev = device;
 		if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return "no HIP device visible: libarachne_amd.so needs an MI355X (there is no CPU fallback)";
 		if (device < 0 || device >= n) return "device index out of range";
 		if (hipSetDevice(device) != hipSuccess) return "hipSetDevice failed";
 		hipDeviceProp_t p;
 		if (hipGetDeviceProperties(&p, device) != hipSuccess) return "hipGetDeviceProperties failed";
 		n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-		if (hipStreamCreate(&stream) != hipSuccess) return "hipStreamCreate failed";
+		if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
 		(void)hipMalloc(&d_total, 8);
+		(void)hipHostMalloc(&pinned, 64, hipHostMallocDefault);
+		hipMemPool_t pool;
+		if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) { uint64_t keep = ~0ull; (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep); }
 		return "";
 	}
 	~HipRT()
 	{
 		if (scan_tmp) hipFree(scan_tmp);
 		if (d_total) hipFree(d_total);
+		if (pinned) (void)hipHostFree(pinned);
 		for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 		for (auto e : free_events) (void)hipEventDestroy(e);
 		if (stream) hipStreamDestroy(stream);
 	}
-	template <class T> T *alloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; }
-	void free(void *p) { if (p) hipFree(p); }
+	// Stream-ordered allocation from the device's default memory pool (kept cached, see init): hipMalloc/hipFree would
+	// synchronise the whole device and serialise the batches that run on other streams.
+	template <class T> T *alloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMallocAsync(&p, (n ? n : 1) * sizeof(T), stream)); return (T *)p; }
+	void free(void *p) { if (p) (void)hipFreeAsync(p, stream); }
 	void h2d(void *d, const void *s, size_t bytes) { if (bytes) { ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream)); ARX_HIP_CHECK(hipStreamSynchronize(stream)); } }
-	void d2h(void *d, const void *s, size_t bytes) { if (bytes) { ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); ARX_HIP_CHECK(hipStreamSynchronize(stream)); } }
+	void d2h(void *d, const void *s, size_t bytes)
+	{
+		if (!bytes) return;
+		if (bytes <= 64 && pinned) { // small read-backs (round counters, error word, scan totals) go through pinned memory
+			ARX_HIP_CHECK(hipMemcpyAsync(pinned, s, bytes, hipMemcpyDeviceToHost, stream));
+			ARX_HIP_CHECK(hipStreamSynchronize(stream));
+			memcpy(d, pinned, bytes);
+			return;
+		}
+		ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream));
+		ARX_HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	void memset0(void *d, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, 0, bytes, stream)); }
 	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }
 

@@ -186,8 +186,10 @@ struct KSwU8 {
 struct KReg2Aln {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *preg_off, *n_regs; int n_reads; const Reg *pregs;
 	Aln *alns; uint32_t *cig; int cig_w; int32_t *eh; int eh_words; uint8_t *z; int z_cap; uint32_t *err;
-	ARX_DEV void operator()(int g, int slot) const
+	int32_t *nw_list, *nw_count; int mode; // mode 0: every region slot, gap-free ones finished inline, the rest queued; mode 1: the queued ones
+	ARX_DEV void operator()(int item, int slot) const
 	{
+		const int g = mode ? nw_list[item] : item;
 		int lo = 0, hi = n_reads;
 		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (preg_off[mid] <= g) lo = mid; else hi = mid; }
 		const int r = lo, j = g - preg_off[r];
@@ -196,6 +198,15 @@ struct KReg2Aln {
 		Aln a = Aln();
 		a.cigar_off = g * cig_w;
 		const int lq = lens[r];
+		if (mode == 0) {
+			// both infer_bw() calls give 0 <=> equal lengths and fewer than 12 score units lost: the CIGAR is one M run (bwa.c:141-149)
+			const int l1 = ar.qe - ar.qb, l2 = (int)(ar.re - ar.rb);
+			const bool gapfree = l1 == l2 && l1 * OPT_A - ar.truesc < ((OPT_O_DEL + OPT_E_DEL - OPT_A) << 1);
+			if (!gapfree) { nw_list[KExtStep::claim(nw_count)] = g; return; }
+			if (!reg2aln(ix, lq, bases + base_off[r], ar, (int32_t *)0, (uint8_t *)0, cig + (size_t)g * cig_w, cig_w, a)) KSeed::atomic_or_err(err, ERR_CIGAR_OVERFLOW);
+			alns[g] = a;
+			return;
+		}
 		// worst-case traceback matrix for this region: n_col <= l_query, rows = re - rb
 		if ((int64_t)(ar.qe - ar.qb) * (ar.re - ar.rb) > z_cap) { KSeed::atomic_or_err(err, ERR_POOL_OVERFLOW); a.n_cigar = 0; a.rid = -1; alns[g] = a; return; }
 		if (!reg2aln(ix, lq, bases + base_off[r], ar, eh + (size_t)slot * eh_words, z + (size_t)slot * z_cap, cig + (size_t)g * cig_w, cig_w, a))
@@ -248,7 +259,7 @@ public:
 		int32_t *next = 0, *iscr = 0, *n_chain = 0, *srt = 0, *idx = 0, *n_core = 0; Chain *ctmp = 0, *cout = 0; BtNode *nodes = 0; Seed *sout = 0;
 		Reg *regs = 0, *rtmp = 0; ExtState *est = 0; ExtTask *etask = 0; ExtRes *eres = 0; int32_t *counter = 0; uint32_t *err = 0;
 		int32_t *eh = 0; int32_t *cap = 0, *preg_off = 0, *n_regs = 0, *pidx = 0; Reg *pregs = 0, *ptmp = 0; ResState *rst = 0; SwTask *stask = 0; U8Res *sres = 0;
-		uint8_t *sw_scr = 0, *z = 0; Aln *alns = 0; uint32_t *cig = 0;
+		uint8_t *sw_scr = 0, *z = 0; Aln *alns = 0; uint32_t *cig = 0; int32_t *nw_list = 0;
 		int64_t T = 0, P = 0; int cig_w = 0;
 	};
 
@@ -256,7 +267,7 @@ public:
 	{
 		void *ptrs[] = { w.intv, w.smem_scr, w.n_intv, w.n_occ, w.occ_off, w.occ_seed, w.next, w.iscr, w.n_chain, w.srt, w.idx, w.n_core, w.ctmp, w.cout,
 		                 w.nodes, w.sout, w.regs, w.rtmp, w.est, w.etask, w.eres, w.counter, w.err, w.eh, w.cap, w.preg_off, w.n_regs, w.pidx, w.pregs,
-		                 w.ptmp, w.rst, w.stask, w.sres, w.sw_scr, w.z, w.alns, w.cig };
+		                 w.ptmp, w.rst, w.stask, w.sres, w.sw_scr, w.z, w.alns, w.cig, w.nw_list };
 		for (void *p : ptrs) if (p) rt.free(p);
 		w = Work();
 	}
@@ -353,18 +364,24 @@ public:
 	// ---- stage 6: CIGAR for every region; retried with wider CIGAR slots if one overflows
 	int stage_reg2aln(const DeviceBatch &b, Work &w)
 	{
-		const int slots = rt.max_slots();
+		const int slots = rt.max_slots_small(); // only the gapped minority needs DP scratch
 		const int eh_words = 2 * (b.max_len + 2);
 		const int z_cap = b.max_len * (2 * b.max_len + 64);
 		const size_t P = (size_t)w.P + 1;
 		w.z = rt.template alloc<uint8_t>((size_t)slots * z_cap);
 		rt.free(w.eh); w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
 		w.alns = rt.template alloc<Aln>(P);
+		w.nw_list = rt.template alloc<int32_t>(P);
 		for (w.cig_w = 16;; w.cig_w *= 2) {
 			if (w.cig) rt.free(w.cig);
 			w.cig = rt.template alloc<uint32_t>(P * w.cig_w);
-			KReg2Aln k{ix, b.bases, b.base_off, b.lens, w.preg_off, w.n_regs, b.n_reads, w.pregs, w.alns, w.cig, w.cig_w, w.eh, eh_words, w.z, z_cap, w.err};
+			rt.memset0(w.counter, 4);
+			KReg2Aln k{ix, b.bases, b.base_off, b.lens, w.preg_off, w.n_regs, b.n_reads, w.pregs, w.alns, w.cig, w.cig_w, w.eh, eh_words, w.z, z_cap, w.err,
+			           w.nw_list, w.counter, 0};
 			rt.launch("reg2aln", (int)w.P, k);
+			const int n_nw = read_counter(w);
+			k.mode = 1;
+			rt.launch_small("reg2aln_nw", n_nw, k);
 			uint32_t e = read_err(w);
 			if (!(e & ERR_CIGAR_OVERFLOW)) return (int)e;
 			if (w.cig_w >= 1024) return (int)e;

@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--pairs-per-barcode", type=int, default=1000)
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
     ap.add_argument("--chunk-pairs", type=int, default=125_000, help="pairs per device batch inside one step")
+    ap.add_argument("--streams", type=int, default=8, help="device batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
@@ -173,9 +174,18 @@ def main():
         start = end
     log(f"rank {rank}: {len(batches)} device batches uploaded")
 
+    # every device batch has its own HIP stream; host threads drive them concurrently so that the step/DP round trips
+    # of one batch overlap the kernels of the others (ctypes releases the GIL inside arx_batch_run)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(1, min(args.streams, len(batches))))
+
     def step():
+        # phase 1: the HBM-bound seeding + locate kernels, one batch after the other (they fill the chip on their own and
+        # their HIP-event time is then the un-overlapped kernel time the roofline is computed from)
         for b in batches:
-            b.run(api.STAGE_ALN)
+            b.run(api.STAGE_SEED)
+        # phase 2: chain .. CIGAR resume from there, all batches in flight
+        list(pool.map(lambda b: b.run(api.STAGE_ALN), batches))
 
     for _ in range(args.warmup):
         step()

@@ -24,6 +24,8 @@ struct SimRT {
 	static const char *name() { return "hostsim"; }
 	std::map<std::string, KernelTimer> tm;
 	std::string init(int) { return ""; }
+	void bind() {}
+	void set_timing(bool) {}
 	// poison fresh memory: hipMalloc does not zero either, so nothing may rely on it
 	template <class T> T *alloc(size_t n) { size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); memset(p, 0xAB, b); return (T *)p; }
 	void free(void *p) { ::free(p); }
