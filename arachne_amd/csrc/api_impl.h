@@ -41,7 +41,7 @@ template <class RT> struct Context {
 		if (!e.empty()) return e;
 		e = load_index(prefix, hix);
 		if (!e.empty()) return e;
-		auto up = [&](const void *src, size_t bytes) { void *d = rt.template alloc<uint8_t>(bytes + 64); rt.h2d(d, src, bytes); dev_index.push_back(d); return d; };
+		auto up = [&](const void *src, size_t bytes) { void *d = rt.template palloc<uint8_t>(bytes + 64); rt.h2d(d, src, bytes); dev_index.push_back(d); return d; };
 		ix.bwt = (const uint32_t *)up(hix.bwt.data(), hix.bwt.size() * 4);
 		ix.sa = (const uint64_t *)up(hix.sa.data(), hix.sa.size() * 8);
 		ix.pac = (const uint8_t *)up(hix.pac.data(), hix.pac.size());
@@ -54,7 +54,7 @@ template <class RT> struct Context {
 		for (auto &n : hix.names) name_ptrs.push_back(n.c_str());
 		return "";
 	}
-	~Context() { for (void *p : dev_index) rt.free(p); }
+	~Context() { for (void *p : dev_index) rt.pfree(p); }
 };
 
 template <class RT> struct Batch {

@@ -57,12 +57,11 @@ struct HipRT {
 		if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
 		(void)hipMalloc(&d_total, 8);
 		(void)hipHostMalloc(&pinned, 64, hipHostMallocDefault);
-		hipMemPool_t pool;
-		if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) { uint64_t keep = ~0ull; (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep); }
 		return "";
 	}
 	~HipRT()
 	{
+		for (auto &sl : slabs) (void)hipFree(sl.p);
 		if (scan_tmp) hipFree(scan_tmp);
 		if (d_total) hipFree(d_total);
 		if (pinned) (void)hipHostFree(pinned);
@@ -70,10 +69,24 @@ struct HipRT {
 		for (auto e : free_events) (void)hipEventDestroy(e);
 		if (stream) hipStreamDestroy(stream);
 	}
-	// Stream-ordered allocation from the device's default memory pool (kept cached, see init): hipMalloc/hipFree would
-	// synchronise the whole device and serialise the batches that run on other streams.
-	template <class T> T *alloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMallocAsync(&p, (n ? n : 1) * sizeof(T), stream)); return (T *)p; }
-	void free(void *p) { if (p) (void)hipFreeAsync(p, stream); }
+	// Work memory of a batch comes from a per-runtime arena: slabs obtained once with hipMalloc, bump-allocated, reset as
+	// a whole when the batch is re-run.  Steady state therefore has no hipMalloc/hipFree at all -- both synchronise the
+	// device and would serialise the batches that run on other streams.
+	struct Slab { char *p; size_t cap, used; };
+	std::vector<Slab> slabs;
+	template <class T> T *alloc(size_t n)
+	{
+		size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255;
+		for (auto &sl : slabs) if (sl.cap - sl.used >= bytes) { char *r = sl.p + sl.used; sl.used += bytes; return (T *)r; }
+		Slab sl; sl.cap = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30); sl.used = bytes;
+		ARX_HIP_CHECK(hipMalloc((void **)&sl.p, sl.cap));
+		slabs.push_back(sl);
+		return (T *)sl.p;
+	}
+	void free(void *) {}                       // arena memory is released by arena_reset()
+	void arena_reset() { for (auto &sl : slabs) sl.used = 0; }
+	template <class T> T *palloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; } // persistent
+	void pfree(void *p) { if (p) (void)hipFree(p); }
 	void h2d(void *d, const void *s, size_t bytes) { if (bytes) { ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream)); ARX_HIP_CHECK(hipStreamSynchronize(stream)); } }
 	void d2h(void *d, const void *s, size_t bytes)
 	{

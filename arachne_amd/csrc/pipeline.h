@@ -243,15 +243,15 @@ public:
 		for (int i = 0; i < n_reads; ++i) { off[i] = (int32_t)tot; tot += lens[i]; if (lens[i] > mx) mx = lens[i]; }
 		off[n_reads] = (int32_t)tot;
 		b.n_reads = n_reads; b.n_bases = tot; b.max_len = mx;
-		b.bases = rt.template alloc<uint8_t>(tot + 16);
-		b.base_off = rt.template alloc<int32_t>(n_reads + 1);
-		b.lens = rt.template alloc<int32_t>(n_reads + 1);
+		b.bases = rt.template palloc<uint8_t>(tot + 16);
+		b.base_off = rt.template palloc<int32_t>(n_reads + 1);
+		b.lens = rt.template palloc<int32_t>(n_reads + 1);
 		rt.h2d(b.bases, bases, tot);
 		rt.h2d(b.base_off, off.data(), sizeof(int32_t) * (n_reads + 1));
 		rt.h2d(b.lens, lens, sizeof(int32_t) * n_reads);
 		return b;
 	}
-	void release(DeviceBatch &b) { rt.free(b.bases); rt.free(b.base_off); rt.free(b.lens); b = DeviceBatch(); }
+	void release(DeviceBatch &b) { rt.pfree(b.bases); rt.pfree(b.base_off); rt.pfree(b.lens); b = DeviceBatch(); }
 
 	// everything that stays on the device between the stages of one batch
 	struct Work {
@@ -269,6 +269,7 @@ public:
 		                 w.nodes, w.sout, w.regs, w.rtmp, w.est, w.etask, w.eres, w.counter, w.err, w.eh, w.cap, w.preg_off, w.n_regs, w.pidx, w.pregs,
 		                 w.ptmp, w.rst, w.stask, w.sres, w.sw_scr, w.z, w.alns, w.cig, w.nw_list };
 		for (void *p : ptrs) if (p) rt.free(p);
+		rt.arena_reset();
 		w = Work();
 	}
 

@@ -29,6 +29,9 @@ struct SimRT {
 	// poison fresh memory: hipMalloc does not zero either, so nothing may rely on it
 	template <class T> T *alloc(size_t n) { size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); memset(p, 0xAB, b); return (T *)p; }
 	void free(void *p) { ::free(p); }
+	template <class T> T *palloc(size_t n) { return alloc<T>(n); }
+	void pfree(void *p) { ::free(p); }
+	void arena_reset() {}
 	void h2d(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void d2h(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void memset0(void *d, size_t b) { memset(d, 0, b); }
