@@ -6,27 +6,56 @@
 
 namespace arx {
 
-// Packed per-word symbol counting.  A 32-bit BWT word holds 16 symbols, MSB first.
-// marks(w, c): bit 2i set iff symbol i (from the LSB side) equals c.
-ARX_DEVI uint32_t sym_marks(uint32_t w, int c)
+// ---- Occ block arithmetic.  A block is 64 bytes: 4 x u64 cumulative counts, then 128 symbols as 8 x u32 (16 symbols
+// each, most significant first).  Two words are fused into one u64 (first word in the high half) so that symbol i of the
+// pair sits at bits 63-2i..62-2i; counting is branch-free: a keep-mask derived from n selects the first n symbols.
+struct OccBlock { uint64_t cum[4]; uint64_t w[4]; };
+
+ARX_DEVI OccBlock load_block(const uint32_t *blk)
 {
-	uint32_t x = w ^ (0x55555555u * (uint32_t)(3 - c)); // symbols equal to c become 0b11
-	return x & (x >> 1) & 0x55555555u;
+	OccBlock b;
+	struct alignas(16) Q16 { uint32_t x, y, z, w; };
+	const Q16 *p = (const Q16 *)blk; // 64-byte aligned: four 16-byte loads (global_load_dwordx4)
+	const Q16 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+	b.cum[0] = (uint64_t)a0.y << 32 | a0.x; b.cum[1] = (uint64_t)a0.w << 32 | a0.z;
+	b.cum[2] = (uint64_t)a1.y << 32 | a1.x; b.cum[3] = (uint64_t)a1.w << 32 | a1.z;
+	b.w[0] = (uint64_t)a2.x << 32 | a2.y; b.w[1] = (uint64_t)a2.z << 32 | a2.w;
+	b.w[2] = (uint64_t)a3.x << 32 | a3.y; b.w[3] = (uint64_t)a3.z << 32 | a3.w;
+	return b;
 }
 
-// counts of A,C,G,T among the first n (0..128) symbols of one 64-byte block (words at blk+8..blk+15)
-ARX_DEVI void block_count(const uint32_t *blk, int n, uint32_t cnt[4])
+// counts of the four symbols among the first n (1..128) symbols of the block
+ARX_DEVI void block_count4(const OccBlock &b, int n, uint32_t cnt[4])
 {
-	cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+	uint32_t c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-	for (int j = 0; j < 8; ++j) {
-		int nj = n - 16 * j;
-		if (nj <= 0) break;
-		uint32_t w = blk[8 + j];
-		uint32_t keep = nj >= 16 ? 0xffffffffu : ~((1u << ((16 - nj) << 1)) - 1);
-#pragma unroll
-		for (int c = 0; c < 4; ++c) cnt[c] += __builtin_popcount(sym_marks(w, c) & keep);
+	for (int j = 0; j < 4; ++j) {
+		int nj = n - 32 * j;                       // symbols of this 64-bit word that count
+		nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj);
+		const uint64_t keep = nj == 0 ? 0 : ~0ull << (64 - 2 * nj);
+		const uint64_t w = b.w[j];
+		const uint64_t lo = w & 0x5555555555555555ull & keep, hi = (w >> 1) & 0x5555555555555555ull & keep;
+		const uint32_t p3 = (uint32_t)__builtin_popcountll(hi & lo);
+		c3 += p3;
+		c2 += (uint32_t)__builtin_popcountll(hi) - p3;
+		c1 += (uint32_t)__builtin_popcountll(lo) - p3;
 	}
+	cnt[1] = c1; cnt[2] = c2; cnt[3] = c3; cnt[0] = (uint32_t)n - c1 - c2 - c3;
+}
+
+ARX_DEVI uint32_t block_count1(const OccBlock &b, int n, int c)
+{
+	uint32_t r = 0;
+	const uint64_t flip_lo = (c & 1) ? 0 : ~0ull, flip_hi = (c & 2) ? 0 : ~0ull;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		int nj = n - 32 * j;
+		nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj);
+		const uint64_t keep = nj == 0 ? 0 : ~0ull << (64 - 2 * nj);
+		const uint64_t w = b.w[j];
+		r += (uint32_t)__builtin_popcountll((w ^ flip_lo) & ((w >> 1) ^ flip_hi) & 0x5555555555555555ull & keep);
+	}
+	return r;
 }
 
 // bwt_occ4 (bwt.c:169-187): counts in B[0..k] of the $-removed BWT.  Touches exactly one 64-byte block.
@@ -34,11 +63,10 @@ ARX_DEVI void occ4(const IndexView &ix, uint64_t k, uint64_t cnt[4])
 {
 	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
 	k -= (k >= ix.primary);
-	const uint32_t *blk = ix.bwt + ((k >> 7) << 4);
-	const uint64_t *cum = (const uint64_t *)blk;
+	const OccBlock b = load_block(ix.bwt + ((k >> 7) << 4));
 	uint32_t c4[4];
-	block_count(blk, (int)(k & 127) + 1, c4);
-	cnt[0] = cum[0] + c4[0]; cnt[1] = cum[1] + c4[1]; cnt[2] = cum[2] + c4[2]; cnt[3] = cum[3] + c4[3];
+	block_count4(b, (int)(k & 127) + 1, c4);
+	cnt[0] = b.cum[0] + c4[0]; cnt[1] = b.cum[1] + c4[1]; cnt[2] = b.cum[2] + c4[2]; cnt[3] = b.cum[3] + c4[3];
 }
 
 // bwt_occ (bwt.c:107-130) for one symbol
@@ -47,17 +75,8 @@ ARX_DEVI uint64_t occ1(const IndexView &ix, uint64_t k, int c)
 	if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
 	if (k == (uint64_t)-1) return 0;
 	k -= (k >= ix.primary);
-	const uint32_t *blk = ix.bwt + ((k >> 7) << 4);
-	int n = (int)(k & 127) + 1;
-	uint32_t cnt = 0;
-#pragma unroll
-	for (int j = 0; j < 8; ++j) {
-		int nj = n - 16 * j;
-		if (nj <= 0) break;
-		uint32_t keep = nj >= 16 ? 0xffffffffu : ~((1u << ((16 - nj) << 1)) - 1);
-		cnt += __builtin_popcount(sym_marks(blk[8 + j], c) & keep);
-	}
-	return ((const uint64_t *)blk)[c] + cnt;
+	const OccBlock b = load_block(ix.bwt + ((k >> 7) << 4));
+	return b.cum[c] + block_count1(b, (int)(k & 127) + 1, c);
 }
 
 // bwt_extend (bwt.c:262-274), returning only the child for symbol c -- the SMEM search never looks at the other three.
@@ -88,130 +107,148 @@ ARX_DEVI Biv set_intv(const IndexView &ix, int c) // bwt_set_intv (bwt.h:78)
 	return ik;
 }
 
-// bwt_sa (bwt.c:86-96) via bwt_invPsi (bwt.c:53-59): LF steps until a sampled row
+// one LF step of bwt_invPsi (bwt.c:53-59)
+ARX_DEVI uint64_t lf_step(const IndexView &ix, uint64_t k)
+{
+	if (k == ix.primary) return 0;
+	const uint64_t x = k - (k > ix.primary);           // row of the $-removed string holding B[k]
+	const OccBlock b = load_block(ix.bwt + ((x >> 7) << 4));
+	const int pos = (int)(x & 127);
+	const int c = (int)(b.w[pos >> 5] >> (62 - 2 * (pos & 31))) & 3;
+	// occ(k, c) counts B[0..x'] with x' = k - (k >= primary); for k != primary that is the same row x (k > primary <=> k >= primary)
+	return ix.L2[c] + b.cum[c] + block_count1(b, pos + 1, c);
+}
+
+// bwt_sa (bwt.c:86-96): LF steps until a sampled row
 ARX_DEVI uint64_t sa_lookup(const IndexView &ix, uint64_t k)
 {
 	uint64_t sa = 0, mask = (uint64_t)ix.sa_intv - 1;
-	while (k & mask) {
-		uint64_t x = k - (k > ix.primary);
-		int c = ix.bwt[((x >> 7) << 4) + 8 + ((x & 127) >> 4)] >> ((~x & 15) << 1) & 3;
-		++sa;
-		k = (k == ix.primary) ? 0 : ix.L2[c] + occ1(ix, k, c);
-	}
+	while (k & mask) { ++sa; k = lf_step(ix, k); }
 	return sa + ix.sa[k / (uint64_t)ix.sa_intv];
 }
 
-// Scratch for one SMEM search: two interval lists of up to len+1 entries each plus the per-call result list.
+// Scratch for the SMEM searches of one read: two interval lists of up to len+1 entries each plus the per-call result list.
 struct SmemScratch { Biv *v0, *v1, *mem; };
 
-// bwt_smem1a with max_intv = 0 (bwt.c:289-351).  Returns the end of the longest match from x; *n_mem SMEMs in sc.mem, sorted by start.
-ARX_DEV int smem1(const IndexView &ix, int len, const uint8_t *q, int x, int min_intv, const SmemScratch &sc, int *n_mem)
+// mem_collect_intv (bwamem.c:114-162): SMEM pass (bwt_smem1a, bwt.c:289-351, max_intv = 0), re-seeding pass from the
+// middle of long rare SMEMs, LAST-like pass (bwt_seed_strategy1, bwt.c:358-379), then sort by info.
+//
+// The reference nests these loops around bwt_extend(); here they are flattened into one state machine that performs at
+// most ONE extend1() per iteration at a single place in the code, so that the 64 reads of a wavefront -- each somewhere
+// else in its own forward/backward search -- reconverge on the only expensive step (two random 64-byte Occ blocks).
+// Entries with equal info describe the same query substring and hence the same bi-interval, so any sort reproduces
+// ks_introsort's result.  Returns the number of intervals written to out (capacity cap); *overflow is set when more were found.
+ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const SmemScratch &sc, Biv *out, int cap, int *overflow)
 {
-	Biv *prev = sc.v0, *curr = sc.v1, *sw, *mem = sc.mem;
-	int i, j, c, ret, n_curr = 0, n_prev, nm = 0;
-	*n_mem = 0;
-	if (q[x] > 3) return x + 1;
-	if (min_intv < 1) min_intv = 1;
-	Biv ik = set_intv(ix, q[x]), ok;
-	ik.info = x + 1;
-	for (i = x + 1; i < len; ++i) { // forward: remember the interval each time its size changes
-		if (q[i] < 4) {
-			ok = extend1(ix, ik, 0, 3 - q[i]);
+	enum { ST_P1_NEXT, ST_P2_NEXT, ST_P3_NEXT, ST_FWD, ST_FWD_DONE, ST_BWD_ROW, ST_BWD_J, ST_SMEM_DONE, ST_STRAT, ST_DONE };
+	Biv *prev = sc.v0, *curr = sc.v1, *mem = sc.mem;
+	int state = ST_P1_NEXT, pass = 1;
+	int n = 0, old_n = 0, k2 = 0;            // output count; pass-2 bookkeeping
+	int x = 0, min_intv = 1, ret = 0;        // current smem1 call
+	int i = 0, j = 0, c = 0, n_prev = 0, n_curr = 0, nm = 0, sx = 0;
+	Biv ik = Biv();
+	while (state != ST_DONE) {
+		Biv req = Biv();
+		int rb = 0, rc = 0;
+		bool need = false;
+		switch (state) {
+		case ST_P1_NEXT:
+			while (x < len && q[x] > 3) ++x;
+			if (x >= len) { old_n = n; k2 = 0; pass = 2; state = ST_P2_NEXT; break; }
+			min_intv = 1; ik = set_intv(ix, q[x]); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
+			break;
+		case ST_P2_NEXT: {
+			bool found = false;
+			while (k2 < old_n) { // re-seed from the middle of SMEMs that are long and occur rarely
+				const Biv p = out[k2];
+				const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
+				if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) { ++k2; continue; }
+				x = (start + end) >> 1; min_intv = (int)p.s + 1;
+				found = true;
+				break;
+			}
+			if (!found) { x = 0; state = ST_P3_NEXT; break; }
+			if (q[x] > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
+			ik = set_intv(ix, q[x]); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
+			break;
+		}
+		case ST_P3_NEXT:
+			while (x < len && q[x] > 3) ++x;
+			if (x >= len) { state = ST_DONE; break; }
+			ik = set_intv(ix, q[x]); sx = x; i = x + 1; state = ST_STRAT;
+			break;
+		case ST_FWD: // forward extension at query position i; the interval is remembered each time its size changes
+			if (i >= len || q[i] > 3) { curr[n_curr++] = ik; state = ST_FWD_DONE; break; }
+			req = ik; rb = 0; rc = 3 - q[i]; need = true;
+			break;
+		case ST_FWD_DONE: {
+			for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
+			ret = (int)curr[0].info;
+			Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+			i = x - 1; state = ST_BWD_ROW;
+			break;
+		}
+		case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
+			if (i < -1) { state = ST_SMEM_DONE; break; }
+			c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1);
+			n_curr = 0; j = 0;
+			if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
+				if (n_prev > 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
+				state = ST_SMEM_DONE;
+				break;
+			}
+			state = ST_BWD_J;
+			break;
+		case ST_BWD_J:
+			if (j >= n_prev) {
+				if (n_curr == 0) { state = ST_SMEM_DONE; break; }
+				Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+				--i; state = ST_BWD_ROW;
+				break;
+			}
+			req = prev[j]; rb = 1; rc = c; need = true;
+			break;
+		case ST_SMEM_DONE:
+			for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
+				const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
+				if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[t]; else *overflow = 1; }
+			}
+			if (pass == 1) { x = ret; state = ST_P1_NEXT; } else { ++k2; state = ST_P2_NEXT; }
+			break;
+		case ST_STRAT: // shortest forward match of > min_seed_len bases occurring < max_mem_intv times
+			if (i >= len) { x = len; state = ST_P3_NEXT; break; }
+			if (q[i] > 3) { x = i + 1; state = ST_P3_NEXT; break; }
+			req = ik; rb = 0; rc = 3 - q[i]; need = true;
+			break;
+		}
+		if (!need) continue;
+		const Biv ok = extend1(ix, req, rb, rc); // the one expensive step
+		if (state == ST_FWD) {
 			if (ok.s != ik.s) {
 				curr[n_curr++] = ik;
-				if (ok.s < (uint64_t)min_intv) break;
+				if (ok.s < (uint64_t)min_intv) { state = ST_FWD_DONE; continue; }
 			}
-			ik = ok; ik.info = i + 1;
-		} else { curr[n_curr++] = ik; break; }
-	}
-	if (i == len) curr[n_curr++] = ik;
-	for (j = 0; j < n_curr >> 1; ++j) { Biv t = curr[n_curr - 1 - j]; curr[n_curr - 1 - j] = curr[j]; curr[j] = t; } // longest first
-	ret = (int)curr[0].info;
-	sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-	for (i = x - 1; i >= -1; --i) { // backward: keep what cannot be extended and is not contained in a longer match
-		c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1);
-		for (j = 0, n_curr = 0; j < n_prev; ++j) {
-			const Biv p = prev[j];
-			if (c >= 0) ok = extend1(ix, p, 1, c);
-			if (c < 0 || ok.s < (uint64_t)min_intv) {
-				if (n_curr == 0) {
-					if (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32) {
-						ik = p; ik.info |= (uint64_t)(i + 1) << 32;
-						mem[nm++] = ik;
-					}
-				}
+			ik = ok; ik.info = i + 1; ++i;
+		} else if (state == ST_BWD_J) {
+			if (ok.s < (uint64_t)min_intv) {
+				if (n_curr == 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
 			} else if (n_curr == 0 || ok.s != curr[n_curr - 1].s) {
-				ok.info = p.info;
-				curr[n_curr++] = ok;
+				Biv t = ok; t.info = req.info;
+				curr[n_curr++] = t;
 			}
-		}
-		if (n_curr == 0) break;
-		sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-	}
-	for (j = 0; j < nm >> 1; ++j) { Biv t = mem[nm - 1 - j]; mem[nm - 1 - j] = mem[j]; mem[j] = t; }
-	*n_mem = nm;
-	return ret;
-}
-
-// bwt_seed_strategy1 (bwt.c:358-379): shortest forward match of >= min_len+1 bases occurring < max_intv times
-ARX_DEV int seed_strategy1(const IndexView &ix, int len, const uint8_t *q, int x, int min_len, int max_intv, Biv *mem)
-{
-	mem->k = mem->l = mem->s = mem->info = 0;
-	if (q[x] > 3) return x + 1;
-	Biv ik = set_intv(ix, q[x]);
-	for (int i = x + 1; i < len; ++i) {
-		if (q[i] < 4) {
-			Biv ok = extend1(ix, ik, 0, 3 - q[i]);
-			if (ok.s < (uint64_t)max_intv && i - x >= min_len) {
-				*mem = ok;
-				mem->info = (uint64_t)x << 32 | (uint32_t)(i + 1);
-				return i + 1;
-			}
-			ik = ok;
-		} else return i + 1;
-	}
-	return len;
-}
-
-// mem_collect_intv (bwamem.c:114-162): three seeding passes, then sort by info.  Entries with equal info describe the same
-// query substring and hence the same bi-interval, so any sort reproduces ks_introsort's result.
-// Returns the number of intervals written to out (capacity cap); sets *overflow when more were found.
-ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *seq, const SmemScratch &sc, Biv *out, int cap, int *overflow)
-{
-	int n = 0, x = 0, nm;
-	while (x < len) {
-		if (seq[x] < 4) {
-			x = smem1(ix, len, seq, x, 1, sc, &nm);
-			for (int i = 0; i < nm; ++i) {
-				int slen = (int)((uint32_t)sc.mem[i].info - (uint32_t)(sc.mem[i].info >> 32));
-				if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = sc.mem[i]; else *overflow = 1; }
-			}
-		} else ++x;
-	}
-	int old_n = n;
-	for (int k = 0; k < old_n; ++k) { // re-seed from the middle of long SMEMs that occur rarely
-		const Biv p = out[k];
-		int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
-		if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) continue;
-		smem1(ix, len, seq, (start + end) >> 1, (int)p.s + 1, sc, &nm);
-		for (int i = 0; i < nm; ++i) {
-			int slen = (int)((uint32_t)sc.mem[i].info - (uint32_t)(sc.mem[i].info >> 32));
-			if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = sc.mem[i]; else *overflow = 1; }
+			++j;
+		} else { // ST_STRAT
+			if (ok.s < (uint64_t)OPT_MAX_MEM_INTV && i - sx >= OPT_MIN_SEED_LEN) {
+				if (ok.s > 0) { Biv t = ok; t.info = (uint64_t)sx << 32 | (uint32_t)(i + 1); if (n < cap) out[n++] = t; else *overflow = 1; }
+				x = i + 1; state = ST_P3_NEXT;
+			} else { ik = ok; ++i; }
 		}
 	}
-	x = 0;
-	while (x < len) { // LAST-like pass
-		if (seq[x] < 4) {
-			Biv m;
-			x = seed_strategy1(ix, len, seq, x, OPT_MIN_SEED_LEN, OPT_MAX_MEM_INTV, &m);
-			if (m.s > 0) { if (n < cap) out[n++] = m; else *overflow = 1; }
-		} else ++x;
-	}
-	for (int i = 1; i < n; ++i) { // insertion sort by info
-		Biv t = out[i];
-		int j = i;
-		while (j > 0 && out[j - 1].info > t.info) { out[j] = out[j - 1]; --j; }
-		out[j] = t;
+	for (int a = 1; a < n; ++a) { // insertion sort by info
+		Biv t = out[a];
+		int b = a;
+		while (b > 0 && out[b - 1].info > t.info) { out[b] = out[b - 1]; --b; }
+		out[b] = t;
 	}
 	return n;
 }

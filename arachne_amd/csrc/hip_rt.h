@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "hip_sw_coop.h"
+#include "hip_fm_coop.h"
 
 namespace arx {
 
@@ -180,6 +181,17 @@ struct HipRT {
 		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
 		if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
 		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	// locate: persistent lanes with wave-level work distribution (hip_fm_coop.h); 32 waves per CU to cover the miss latency
+	template <class F> void run_locate(const char *nm, int n, const F &f, int32_t *counter)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch(nm, n, f); return; }
+		memset0(counter, 4);
+		Scope sc(*this, nm, n);
+		int blocks = (n + 255) / 256; if (blocks > n_cu * 8) blocks = n_cu * 8;
+		hipLaunchKernelGGL(k_locate_dyn, dim3(blocks), dim3(256), 0, stream, f.ix, f.occ_seed, n, counter);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// banded extension: 16 lanes per extension (hip_sw_coop.h)

@@ -41,31 +41,30 @@ struct KSeed {
 	static ARX_DEVI void atomic_or_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); }
 };
 
-// one thread per seed occurrence: which read / interval / rank, then the sampled-SA walk (bwamem.c:273-283)
-struct KLocate {
-	IndexView ix; const Biv *intv; const int32_t *n_intv; const int32_t *occ_off; int n_reads; Seed *occ_seed;
-	ARX_DEV void operator()(int g, int) const
+// per read: expand its intervals into seed occurrences (bwamem.c:273-283): at most max_occ rows per interval, evenly
+// strided; the SA row goes to Seed::rbeg until KLocate replaces it by the reference position
+struct KOccFill {
+	const Biv *intv; const int32_t *n_intv, *occ_off; Seed *occ_seed;
+	ARX_DEV void operator()(int r, int) const
 	{
-		int lo = 0, hi = n_reads; // last r with occ_off[r] <= g
-		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (occ_off[mid] <= g) lo = mid; else hi = mid; }
-		const int r = lo;
-		int local = g - occ_off[r];
 		const Biv *iv = intv + (size_t)r * CAP_INTV;
+		int g = occ_off[r];
 		for (int i = 0; i < n_intv[r]; ++i) {
 			const Biv p = iv[i];
-			int cnt = p.s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)p.s;
-			if (local < cnt) {
-				uint64_t step = p.s > (uint64_t)OPT_MAX_OCC ? p.s / OPT_MAX_OCC : 1;
-				Seed s;
-				s.rbeg = (int64_t)sa_lookup(ix, p.k + (uint64_t)local * step);
-				s.qbeg = (int32_t)(p.info >> 32);
-				s.len = (int32_t)((uint32_t)p.info - (uint32_t)(p.info >> 32));
-				occ_seed[g] = s;
-				return;
-			}
-			local -= cnt;
+			const int cnt = p.s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)p.s;
+			const uint64_t step = p.s > (uint64_t)OPT_MAX_OCC ? p.s / OPT_MAX_OCC : 1;
+			Seed s;
+			s.qbeg = (int32_t)(p.info >> 32);
+			s.len = (int32_t)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+			for (int k = 0; k < cnt; ++k) { s.rbeg = (int64_t)(p.k + (uint64_t)k * step); occ_seed[g++] = s; }
 		}
 	}
+};
+
+// one seed occurrence: sampled-SA walk (bwt_sa, bwt.c:86-96)
+struct KLocate {
+	IndexView ix; Seed *occ_seed;
+	ARX_DEV void operator()(int g, int) const { occ_seed[g].rbeg = (int64_t)sa_lookup(ix, (uint64_t)occ_seed[g].rbeg); }
 };
 
 struct KChain {
@@ -291,7 +290,12 @@ public:
 		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
 		w.T = total;
 		w.occ_seed = rt.template alloc<Seed>(w.T + 1);
-		if (w.T) { KLocate kl{ix, w.intv, w.n_intv, w.occ_off, R, w.occ_seed}; rt.launch("locate", (int)w.T, kl); }
+		if (w.T) {
+			KOccFill kf{w.intv, w.n_intv, w.occ_off, w.occ_seed};
+			rt.launch("occ_fill", R, kf);
+			KLocate kl{ix, w.occ_seed};
+			rt.run_locate("locate", (int)w.T, kl, w.counter);
+		}
 		return 0;
 	}
 
