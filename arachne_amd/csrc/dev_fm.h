@@ -151,6 +151,9 @@ ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const S
 		Biv req = Biv();
 		int rb = 0, rc = 0;
 		bool need = false;
+		// bookkeeping runs per lane until this read needs its next extension (or is finished); the lanes of a wave then
+		// reconverge on extend1() below instead of alternating between bookkeeping and extension iterations
+		do {
 		switch (state) {
 		case ST_P1_NEXT:
 			while (x < len && q[x] > 3) ++x;
@@ -221,7 +224,8 @@ ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const S
 			req = ik; rb = 0; rc = 3 - q[i]; need = true;
 			break;
 		}
-		if (!need) continue;
+		} while (!need && state != ST_DONE);
+		if (!need) break;
 		const Biv ok = extend1(ix, req, rb, rc); // the one expensive step
 		if (state == ST_FWD) {
 			if (ok.s != ik.s) {

@@ -13,21 +13,34 @@
 
 namespace arx {
 
-__device__ __forceinline__ int g16_shift_up(int v, int l) // lane l of each 16-lane row receives lane l-1's value, lane 0 receives 0
+// Cross-lane traffic inside a 16-lane group uses DPP row operations (a DPP "row" is exactly 16 lanes): they are VALU
+// operand modifiers with no LDS round trip, unlike __shfl (ds_bpermute), whose latency dominated the first version of
+// these kernels (profiles/r01).  update_dpp(old, src, ctrl, 0xf, 0xf, false): lanes whose source lane falls outside the
+// row keep `old`.
+constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_ROR = 0x120; // + shift amount 1..15
+template <int CTRL> __device__ __forceinline__ int dpp_row(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+
+__device__ __forceinline__ int g16_shift_up(int v, int) // lane l of each 16-lane row receives lane l-1's value, lane 0 receives 0
 {
-	int r = __shfl_up(v, 1, 16);
-	return l == 0 ? 0 : r;
+	return dpp_row<DPP_ROW_SHR + 1>(0, v);
 }
-__device__ __forceinline__ int g16_max(int v)
+template <int N> __device__ __forceinline__ int g16_shift_up_n(int v, int fill) { return dpp_row<DPP_ROW_SHR + N>(fill, v); }
+__device__ __forceinline__ int g16_max(int v) // butterfly by row rotations: every lane ends up with the group maximum
 {
-#pragma unroll
-	for (int o = 8; o; o >>= 1) { int t = __shfl_xor(v, o, 16); v = v > t ? v : t; }
+	int t;
+	t = dpp_row<DPP_ROW_ROR + 8>(v, v); v = v > t ? v : t;
+	t = dpp_row<DPP_ROW_ROR + 4>(v, v); v = v > t ? v : t;
+	t = dpp_row<DPP_ROW_ROR + 2>(v, v); v = v > t ? v : t;
+	t = dpp_row<DPP_ROW_ROR + 1>(v, v); v = v > t ? v : t;
 	return v;
 }
 __device__ __forceinline__ int g16_min(int v)
 {
-#pragma unroll
-	for (int o = 8; o; o >>= 1) { int t = __shfl_xor(v, o, 16); v = v < t ? v : t; }
+	int t;
+	t = dpp_row<DPP_ROW_ROR + 8>(v, v); v = v < t ? v : t;
+	t = dpp_row<DPP_ROW_ROR + 4>(v, v); v = v < t ? v : t;
+	t = dpp_row<DPP_ROW_ROR + 2>(v, v); v = v < t ? v : t;
+	t = dpp_row<DPP_ROW_ROR + 1>(v, v); v = v < t ? v : t;
 	return v;
 }
 __device__ __forceinline__ bool g16_all(bool p)
@@ -234,11 +247,12 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 			if (act) { int key = tv + j; pm = pm > key ? pm : key; }
 		}
 		// exclusive prefix maximum of the lane maxima across the group
-		int x = pm;
-#pragma unroll
-		for (int o = 1; o < 16; o <<= 1) { int y = __shfl_up(x, o, 16); if (l >= o) x = x > y ? x : y; }
-		int ex = __shfl_up(x, 1, 16);
-		if (l == 0) ex = NEG;
+		int x = pm, y;
+		y = g16_shift_up_n<1>(x, NEG); x = x > y ? x : y;
+		y = g16_shift_up_n<2>(x, NEG); x = x > y ? x : y;
+		y = g16_shift_up_n<4>(x, NEG); x = x > y ? x : y;
+		y = g16_shift_up_n<8>(x, NEG); x = x > y ? x : y;
+		const int ex = g16_shift_up_n<1>(x, NEG);
 		// sweep 2: F, H, E and the lane's row maximum (largest column wins ties, ksw.c:437)
 		int m_loc = -1, mj_loc = -1;
 #pragma unroll
@@ -261,7 +275,7 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 		int last_h = 0;
 #pragma unroll
 		for (int u = 0; u < C; ++u) if (u == Cw - 1) last_h = hv[u];
-		const int from_prev = __shfl_up(last_h, 1, 16);
+		const int from_prev = g16_shift_up_n<1>(last_h, 0);
 #pragma unroll
 		for (int u = C - 1; u >= 0; --u) {
 			const int j = c0 + u;
