@@ -123,8 +123,8 @@ def main():
     ap.add_argument("--barcodes", type=int, default=1000)
     ap.add_argument("--pairs-per-barcode", type=int, default=1000)
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
-    ap.add_argument("--chunk-pairs", type=int, default=125_000, help="pairs per device batch inside one step")
-    ap.add_argument("--streams", type=int, default=8, help="device batches in flight (one HIP stream + host thread each)")
+    ap.add_argument("--chunk-pairs", type=int, default=350_000, help="pairs per device batch inside one step")
+    ap.add_argument("--streams", type=int, default=3, help="device batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
