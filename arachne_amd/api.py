@@ -27,6 +27,10 @@ ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev"
 CHAIN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n", "<i4"), ("seed_off", "<i4"), ("w", "<i4"), ("kept", "<i4"), ("first", "<i4"),
                         ("is_alt", "<i4"), ("head", "<i4"), ("tail", "<i4"), ("frac_rep", "<f4")])
 SEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+CAND_DTYPE = np.dtype([("pos", "<i8"), ("aend", "<i8"), ("sum_move", "<f8"), ("reg", "<i4"), ("read", "<i4"), ("rid", "<i4"), ("reversed", "<i4"),
+                       ("score", "<i4"), ("mismatches", "<i4"), ("indels", "<i4"), ("soft_clipped", "<i4"), ("soft_clipped_length", "<i4"),
+                       ("lap2", "<i4"), ("active", "<i4"), ("is_proper", "<i4"), ("mapq", "<i4"), ("molecule_id", "<i4"), ("active_molecule", "<i4"),
+                       ("in_filtered", "<i4"), ("best_in_mol", "<i4"), ("pad", "<i4")])
 CAP_INTV = 256
 STAGE_SEED, STAGE_CHAIN, STAGE_EXTEND, STAGE_RESCUE, STAGE_ALN = 1, 2, 3, 4, 5
 
@@ -67,6 +71,8 @@ def _load(path):
     lib.arx_batch_debug_intv.argtypes = [vp, vp, vp, vp]
     lib.arx_batch_debug_chains.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.arx_batch_debug_core.argtypes = [vp, vp, vp, vp]
+    lib.arx_batch_rfa.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.arx_batch_rfa_fetch.argtypes = [vp, vp, vp, vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     return lib
@@ -134,6 +140,23 @@ class Batch:
         rg = np.zeros(max(T, 1), dtype=REG_DTYPE)
         self.ref._check(self.ref.lib.arx_batch_debug_core(self.ref.h, self.h, n.ctypes.data, rg.ctypes.data))
         return n, rg
+
+    def rfa(self, bc_pair_off, do_rfa, penalty=-4, centromeres=None):
+        """The Go half for this batch (needs run(STAGE_ALN)): per-barcode joint placement and MAPQ.
+        -> dict(cand_off, cands) with one record per candidate (see arx_cand)."""
+        bco = np.ascontiguousarray(bc_pair_off, dtype=np.int64)
+        flags = np.ascontiguousarray(do_rfa, dtype=np.uint8)
+        cs = ce = None
+        if centromeres is not None:
+            cs = np.ascontiguousarray(centromeres[0], dtype=np.int64)
+            ce = np.ascontiguousarray(centromeres[1], dtype=np.int64)
+        n = C.c_int64()
+        self.ref._check(self.ref.lib.arx_batch_rfa(self.ref.h, self.h, len(bco) - 1, bco.ctypes.data, flags.ctypes.data, int(penalty),
+                                                   cs.ctypes.data if cs is not None else None, ce.ctypes.data if ce is not None else None, C.byref(n)))
+        off = np.zeros(self.n_reads + 1, dtype=np.int32)
+        cands = np.zeros(n.value, dtype=CAND_DTYPE)
+        self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, off.ctypes.data, cands.ctypes.data))
+        return dict(cand_off=off, cands=cands)
 
     def free(self):
         if self.h:

@@ -14,6 +14,7 @@
 #include "index_io.h"
 #include "index_build.h"
 #include "pipeline.h"
+#include "pipeline_rfa.h"
 
 namespace arx {
 
@@ -66,6 +67,8 @@ template <class RT> struct Batch {
 	BatchResult res;
 	bool downloaded = false;
 	int done_stage = 0;
+	std::vector<int32_t> lens_host;
+	RfaResult rfa;
 	explicit Batch(Context<RT> *c) : ctx(c), pipe(rt, c->ix)
 	{
 		std::string e = rt.init(c->device);
@@ -135,7 +138,7 @@ template <class RT> struct Batch {
 		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
 		for (int i = 0; i < n_reads; ++i)                                                                                           \
 			if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; }     \
-		ARX_TRY(c, Bat *b = new Bat(c); b->rt.bind(); b->db = b->pipe.upload(bases, lens, n_reads); *out = (arx_batch *)b;)         \
+		ARX_TRY(c, Bat *b = new Bat(c); b->rt.bind(); b->db = b->pipe.upload(bases, lens, n_reads); b->lens_host.assign(lens, lens + n_reads); *out = (arx_batch *)b;) \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_run(arx_ctx *h, arx_batch *bh, int32_t last_stage)                                                                \
@@ -183,6 +186,26 @@ template <class RT> struct Batch {
 		memcpy(regs, b->res.regs.data(), sizeof(arx::Reg) * b->res.regs.size());                                                    \
 		memcpy(alns, b->res.alns.data(), sizeof(arx::Aln) * b->res.alns.size());                                                    \
 		memcpy(cigars, b->res.cigars.data(), 4 * b->res.cigars.size());                                                             \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_rfa(arx_ctx *h, arx_batch *bh, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int32_t penalty, \
+	                  const int64_t *cen_start, const int64_t *cen_end, int64_t *n_cands)                                           \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.alns) { c->set_error("arx_batch_rfa before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }                 \
+		if (n_barcodes <= 0 || bc_pair_off[0] != 0 || 2 * bc_pair_off[n_barcodes] != b->db.n_reads) { c->set_error("barcode offsets must cover the batch"); return ARX_E_ARG; } \
+		ARX_TRY(c, b->rt.bind(); b->rt.set_timing(c->timing);                                                                       \
+			arx::RfaStage<RT>::run(b->pipe, b->db, b->work, n_barcodes, bc_pair_off, do_rfa, penalty, cen_start, cen_end, b->lens_host.data(), b->rfa); \
+			*n_cands = (int64_t)b->rfa.cands.size();)                                                                               \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_rfa_fetch(arx_ctx *h, arx_batch *bh, int32_t *cand_off, arx_cand *cands)                                          \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (b->rfa.cand_off.empty()) { c->set_error("arx_batch_rfa_fetch before arx_batch_rfa"); return ARX_E_ARG; }                \
+		static_assert(sizeof(arx_cand) == sizeof(arx::Cand), "C-ABI structs must mirror the device structs");                       \
+		memcpy(cand_off, b->rfa.cand_off.data(), 4 * b->rfa.cand_off.size());                                                       \
+		memcpy(cands, b->rfa.cands.data(), sizeof(arx::Cand) * b->rfa.cands.size());                                                \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_debug_intv(arx_ctx *h, arx_batch *bh, int32_t *n_intv, uint64_t *intv4)                                           \

@@ -74,6 +74,23 @@ int arx_batch_counts(arx_ctx *ctx, arx_batch *b, int64_t *counts);
 int arx_batch_fetch(arx_ctx *ctx, arx_batch *b, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars);
 void arx_batch_free(arx_ctx *ctx, arx_batch *b);
 
+/* ---- the Go half of the per-barcode path (src/aligner/aligner.go): candidates per read (GetChains :1633, GetAlignments :1484),
+ * tagBestAlignments :1397, inferMolecules :1300 ... optimizer.Optimize (src/optimizer/optimizer.go:15) and estimateMapQualities :797.
+ * Needs arx_batch_run(..., ARX_STAGE_ALN) first.  One candidate per region, or one placeholder (reg = -1, pos = -1) for a read
+ * without regions; `active` marks the placement chosen for the read, `mapq` is set on active candidates. */
+typedef struct {
+	int64_t pos, aend;              /* Alignment.pos / .aend (0-based, reverse-strand candidates swapped +1, aligner.go:1577-1582) */
+	double sum_move;                /* 1 + sum of 10^fastScore over sink molecules (method 2) */
+	int32_t reg, read, rid, reversed, score, mismatches, indels, soft_clipped, soft_clipped_length;
+	int32_t lap2;                   /* log_alignment_probability * 2 */
+	int32_t active, is_proper, mapq, molecule_id, active_molecule, in_filtered /* score >= best - 17 */, best_in_mol, pad;
+} arx_cand;
+/* bc_pair_off[n_barcodes+1]: pair offsets of the (whole) barcodes in the batch; do_rfa[b]: worthRunningRFA (aligner.go:1018-1030),
+ * decided by the caller from the barcode string; penalty: -i (integer, default -4); cen_start/cen_end per contig or NULL. */
+int arx_batch_rfa(arx_ctx *ctx, arx_batch *b, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int32_t penalty,
+                  const int64_t *cen_start, const int64_t *cen_end, int64_t *n_cands);
+int arx_batch_rfa_fetch(arx_ctx *ctx, arx_batch *b, int32_t *cand_off /* n_reads+1 */, arx_cand *cands /* n_cands */);
+
 /* intermediate results for parity tests (device -> host copies of stage outputs) */
 #define ARX_CAP_INTV 256
 int arx_batch_debug_intv(arx_ctx *ctx, arx_batch *b, int32_t *n_intv, uint64_t *intv4 /* n_reads*ARX_CAP_INTV*4 */);

@@ -64,6 +64,14 @@ int64_t ora_fetch_seq(ora_ctx_t *c, int64_t *beg, int64_t mid, int64_t *end, int
 double ora_batch_run(ora_ctx_t *c, int64_t n_pairs, const uint8_t *seqs, const int32_t *lens, int score_delta, int n_threads);
 void ora_batch_get(ora_ctx_t *c, int64_t *n_reads, int64_t *n_regs, int64_t *n_cig, int64_t **reg_off, int64_t **regs, int64_t **alns, uint32_t **cigars);
 
+/* the Go half (arx_oracle_rfa.c): candidate post-processing, RFA placement, MAPQ.  Row layout ORA_CAND_W = 18 int64:
+ * reg read pos aend reversed rid score mismatches indels soft_clipped soft_clipped_length lap2 active is_proper mapq
+ * molecule_id active_molecule in_filtered */
+#define ORA_CAND_W 18
+int64_t ora_rfa(int64_t n_reads, const int64_t *reg_off, const int64_t *regs, const int64_t *alns, const uint32_t *cigars, const int32_t *lens,
+                int n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int penalty, int64_t l_pac, const int64_t *ann_off,
+                const int64_t *cen_start, const int64_t *cen_end, int64_t *cand_rows, int64_t *cand_off);
+
 #ifdef __cplusplus
 }
 #endif

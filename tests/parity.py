@@ -71,3 +71,23 @@ def check_core(batch, ora, seqs, lens, reads=None):
         exp = ora.align1(flat[off[r]:off[r + 1]])
         got = regs_to_rows(rg[occ_off[r]:occ_off[r] + n_core[r]])
         assert got.shape == exp.shape and (got == exp).all(), f"core regions differ for read {r}:\n{got}\n{exp}"
+
+
+RFA_FIELDS = [("reg", 0), ("read", 1), ("pos", 2), ("aend", 3), ("reversed", 4), ("rid", 5), ("score", 6), ("mismatches", 7), ("indels", 8),
+              ("soft_clipped", 9), ("soft_clipped_length", 10), ("lap2", 11), ("active", 12), ("is_proper", 13), ("mapq", 14),
+              ("molecule_id", 15), ("active_molecule", 16), ("in_filtered", 17)]
+
+
+def check_rfa(dev, ora):
+    """dev: Batch.rfa() dict; ora: rfadrv.oracle_rfa() dict.  Every candidate field, bit for bit (MAPQ only on active candidates)."""
+    assert (dev["cand_off"].astype(np.int64) == ora["cand_off"]).all(), "candidate counts per read differ"
+    d, o = dev["cands"], ora["cands"]
+    assert len(d) == len(o)
+    for name, col in RFA_FIELDS:
+        a, b = d[name].astype(np.int64), o[:, col]
+        if name == "mapq":
+            m = o[:, 12] == 1
+            a, b = a[m], b[m]
+        if not (a == b).all():
+            i = int(np.argwhere(a != b)[0][0])
+            raise AssertionError(f"candidate field {name} differs at row {i}: dev {a[i]} ora {b[i]}")
