@@ -141,9 +141,9 @@ class Batch:
         self.ref._check(self.ref.lib.arx_batch_debug_core(self.ref.h, self.h, n.ctypes.data, rg.ctypes.data))
         return n, rg
 
-    def rfa(self, bc_pair_off, do_rfa, penalty=-4, centromeres=None):
+    def rfa(self, bc_pair_off, do_rfa, penalty=-4, centromeres=None, fetch=True):
         """The Go half for this batch (needs run(STAGE_ALN)): per-barcode joint placement and MAPQ.
-        -> dict(cand_off, cands) with one record per candidate (see arx_cand)."""
+        -> dict(cand_off, cands) with one record per candidate (see arx_cand); fetch=False leaves the records in the library."""
         bco = np.ascontiguousarray(bc_pair_off, dtype=np.int64)
         flags = np.ascontiguousarray(do_rfa, dtype=np.uint8)
         cs = ce = None
@@ -153,6 +153,8 @@ class Batch:
         n = C.c_int64()
         self.ref._check(self.ref.lib.arx_batch_rfa(self.ref.h, self.h, len(bco) - 1, bco.ctypes.data, flags.ctypes.data, int(penalty),
                                                    cs.ctypes.data if cs is not None else None, ce.ctypes.data if ce is not None else None, C.byref(n)))
+        if not fetch:
+            return int(n.value)
         off = np.zeros(self.n_reads + 1, dtype=np.int32)
         cands = np.zeros(n.value, dtype=CAND_DTYPE)
         self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, off.ctypes.data, cands.ctypes.data))
@@ -168,6 +170,11 @@ class Batch:
             self.free()
         except Exception:
             pass
+
+
+def worth_running_rfa(barcode: str, n_pairs: int, unique: bool = True) -> bool:
+    """worthRunningRFA (aligner.go:1018-1030): the barcode came through unique, has a '-' in it, and holds at least 5 pairs."""
+    return bool(unique and n_pairs >= 5 and len(barcode.split("-")) >= 2)
 
 
 class Reference:

@@ -69,6 +69,7 @@ template <class RT> struct Batch {
 	int done_stage = 0;
 	std::vector<int32_t> lens_host;
 	RfaResult rfa;
+	std::vector<size_t> rfa_mark; bool rfa_marked = false; // arena state after ARX_STAGE_ALN: a repeated arx_batch_rfa reuses the same memory
 	explicit Batch(Context<RT> *c) : ctx(c), pipe(rt, c->ix)
 	{
 		std::string e = rt.init(c->device);
@@ -149,7 +150,7 @@ template <class RT> struct Batch {
 			b->rt.set_timing(c->timing);                                                                                            \
 			/* stages already done are kept (run(SEED) then run(ALN) resumes); asking for a stage again restarts the batch */       \
 			if (last_stage <= b->done_stage) { b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; }        \
-			b->downloaded = false;                                                                                                  \
+			b->downloaded = false; b->rfa_marked = false;                                                                           \
 			if (b->done_stage < ARX_STAGE_SEED) {                                                                                   \
 				int rc = b->pipe.stage_seed(b->db, b->work);                                                                        \
 				if (rc == -2) { c->set_error("batch too large: seed occurrences exceed 2^30, split the batch"); return ARX_E_TOO_LARGE; } \
@@ -195,6 +196,7 @@ template <class RT> struct Batch {
 		if (!b->work.alns) { c->set_error("arx_batch_rfa before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }                 \
 		if (n_barcodes <= 0 || bc_pair_off[0] != 0 || 2 * bc_pair_off[n_barcodes] != b->db.n_reads) { c->set_error("barcode offsets must cover the batch"); return ARX_E_ARG; } \
 		ARX_TRY(c, b->rt.bind(); b->rt.set_timing(c->timing);                                                                       \
+			if (b->rfa_marked) b->rt.arena_rewind(b->rfa_mark); else { b->rfa_mark = b->rt.arena_mark(); b->rfa_marked = true; }    \
 			arx::RfaStage<RT>::run(b->pipe, b->db, b->work, n_barcodes, bc_pair_off, do_rfa, penalty, cen_start, cen_end, b->lens_host.data(), b->rfa); \
 			*n_cands = (int64_t)b->rfa.cands.size();)                                                                               \
 		return ARX_OK;                                                                                                              \

@@ -11,6 +11,7 @@
 #ifndef ARX_DEV
 #define ARX_DEV __device__
 #define ARX_DEVI __device__ __forceinline__
+#define ARX_HDI __host__ __device__ __forceinline__ // also used by the host tail of a stage
 #define ARX_ATOMIC_OR(p, v) atomicOr((unsigned int *)(p), (unsigned int)(v))
 #define ARX_ATOMIC_INC(p) atomicAdd((int *)(p), 1)
 #endif

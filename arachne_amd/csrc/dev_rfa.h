@@ -30,13 +30,13 @@ struct RfaBarcodeOut { double dna_len; int32_t n_mol, pad; };
 
 constexpr int RFA_P10_HALF = 1400; // table of 10^(x/2) for x in [-1400, 1400]; beyond it pow() underflows to 0 / overflows to inf
 
-ARX_DEVI bool cand_is_pair(const Cand &a, const Cand &b) // isPair
+ARX_HDI bool cand_is_pair(const Cand &a, const Cand &b) // isPair
 {
 	if (a.reversed == b.reversed || a.rid != b.rid) return false;
 	const int64_t dist = a.reversed ? a.pos - b.pos : b.pos - a.pos; // reverse.pos - forward.pos
 	return dist >= -35 && dist < 750;
 }
-ARX_DEVI int cand_pair_score2(const Cand &a, const Cand &m, int pen2) // scoreAlignment without the molecule term
+ARX_HDI int cand_pair_score2(const Cand &a, const Cand &m, int pen2) // scoreAlignment without the molecule term
 {
 	return a.lap2 + m.lap2 + (cand_is_pair(a, m) ? 0 : pen2);
 }
@@ -155,7 +155,7 @@ struct SortByMolRead { // (molecule, read, position rank)
 };
 
 // One barcode.  scratch: rfa_scratch_words(n_c, n_reads, n_seqs) int32.  p10h: table of 10^(x/2), index x + RFA_P10_HALF.
-ARX_DEVI int64_t rfa_scratch_words(int n_c, int n_reads, int n_seqs) { return 7 * (int64_t)n_c + 2 + n_reads + n_seqs + 2; }
+ARX_HDI int64_t rfa_scratch_words(int n_c, int n_reads, int n_seqs) { return 7 * (int64_t)n_c + 2 + n_reads + n_seqs + 2; }
 
 ARX_DEV void rfa_barcode(Cand *c, const int32_t *roff, int n_reads, int n_c, int read0, int do_rfa, int pen_int, int n_seqs,
                          const double *p10h, int32_t *scratch, RfaBarcodeOut *out)

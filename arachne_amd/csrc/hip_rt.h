@@ -86,6 +86,8 @@ struct HipRT {
 	}
 	void free(void *) {}                       // arena memory is released by arena_reset()
 	void arena_reset() { for (auto &sl : slabs) sl.used = 0; }
+	std::vector<size_t> arena_mark() const { std::vector<size_t> m; for (auto &sl : slabs) m.push_back(sl.used); return m; }
+	void arena_rewind(const std::vector<size_t> &m) { for (size_t i = 0; i < slabs.size(); ++i) slabs[i].used = i < m.size() ? m[i] : 0; }
 	template <class T> T *palloc(size_t n) { void *p = 0; ARX_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; } // persistent
 	void pfree(void *p) { if (p) (void)hipFree(p); }
 	void h2d(void *d, const void *s, size_t bytes) { if (bytes) { ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream)); ARX_HIP_CHECK(hipStreamSynchronize(stream)); } }

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- paired reads/s through the MI355X hot path (BASELINE.json metric), one process per GPU.
 
-A "step" = one pass of the whole per-pair path (seed -> locate -> chain -> extend -> rescue -> CIGAR, i.e. what the
-reference does in GetChains + GetAlignments per barcode) over the workload of BASELINE.json configs[1]:
+A "step" = one pass of the whole per-barcode path (seed -> locate -> chain -> extend -> rescue -> CIGAR -> candidate
+statistics -> RFA joint placement -> MAPQ, i.e. what the reference does per barcode in GetChains + GetAlignments +
+tagBestAlignments .. estimateMapQualities, aligner.go:450-490) over the workload of BASELINE.json configs[1]:
 a chr20-sized synthetic genome (64,444,167 bp) and 1,000 barcodes x 1,000 pairs of 2x150 bp haplotagging-style reads.
 Reads are uploaded to HBM before the timed region; results stay in HBM (PCIe-inclusive numbers: DESIGN.md).
 
@@ -127,6 +128,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="device batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
     ap.add_argument("--lib", default=None, help="(dry runs of this script only) alternative library exporting the C ABI")
     args = ap.parse_args()
@@ -170,7 +172,10 @@ def main():
         while end < len(po) - 1 and po[end + 1] - po[start] <= args.chunk_pairs:
             end += 1
         p0, p1 = int(po[start]), int(po[end])
-        batches.append(ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1]))
+        b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1])
+        b.bc_pair_off = (po[start:end + 1] - po[start]).astype(np.int64)
+        b.do_rfa = np.array([api.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(start, end)], dtype=np.uint8)
+        batches.append(b)
         start = end
     log(f"rank {rank}: {len(batches)} device batches uploaded")
 
@@ -184,8 +189,12 @@ def main():
         # their HIP-event time is then the un-overlapped kernel time the roofline is computed from)
         for b in batches:
             b.run(api.STAGE_SEED)
-        # phase 2: chain .. CIGAR resume from there, all batches in flight
-        list(pool.map(lambda b: b.run(api.STAGE_ALN), batches))
+        # phase 2: chain .. CIGAR resume from there, then the per-barcode RFA placement + MAPQ; all batches in flight
+        def rest(b):
+            b.run(api.STAGE_ALN)
+            if not args.no_rfa:
+                b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
+        list(pool.map(rest, batches))
 
     for _ in range(args.warmup):
         step()
@@ -207,7 +216,7 @@ def main():
     if rank == 0:
         pairs_per_step = rs.n_pairs * world
         value = pairs_per_step * args.steps / dt
-        out = dict(metric="paired reads/sec through the per-barcode alignment path (seed+extend+rescue+CIGAR), GRCh38 chr20-size, 2x150bp",
+        out = dict(metric="paired reads/sec through the per-barcode alignment path (seed+extend+rescue+CIGAR%s), GRCh38 chr20-size, 2x150bp" % ("" if args.no_rfa else "+RFA placement+MAPQ"),
                    value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1000.0 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u8/i16/i32 integer (max-plus DP) + u64 (FM-index)", data="synthetic",

@@ -14,6 +14,7 @@
 #include <vector>
 #define ARX_DEV
 #define ARX_DEVI inline
+#define ARX_HDI inline
 #define ARX_ATOMIC_OR(p, v) (*(p) |= (v))
 #define ARX_ATOMIC_INC(p) ((*(p))++)
 #include "../../arachne_amd/csrc/arx_dev.h"
@@ -32,6 +33,8 @@ struct SimRT {
 	template <class T> T *palloc(size_t n) { return alloc<T>(n); }
 	void pfree(void *p) { ::free(p); }
 	void arena_reset() {}
+	std::vector<size_t> arena_mark() const { return {}; }
+	void arena_rewind(const std::vector<size_t> &) {}
 	void h2d(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void d2h(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void memset0(void *d, size_t b) { memset(d, 0, b); }

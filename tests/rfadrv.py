@@ -11,9 +11,7 @@ CAND_FIELDS = ["reg", "read", "pos", "aend", "reversed", "rid", "score", "mismat
                "lap2", "active", "is_proper", "mapq", "molecule_id", "active_molecule", "in_filtered"]
 
 
-def worth_running_rfa(barcode: str, n_pairs: int, unique: bool = True) -> bool:
-    """worthRunningRFA (aligner.go:1018-1030): unique barcode, a '-' in it, at least 5 pairs."""
-    return bool(unique and n_pairs >= 5 and len(barcode.split("-")) >= 2)
+from arachne_amd.api import worth_running_rfa  # noqa: E402,F401  (host logic of the product, re-exported for the tests)
 
 
 def oracle_rfa(batch, lens, bc_pair_off, do_rfa, l_pac, ann_off, penalty=-4, centromeres=None):
