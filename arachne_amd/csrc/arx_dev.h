@@ -14,6 +14,13 @@
 #define ARX_HDI __host__ __device__ __forceinline__ // also used by the host tail of a stage
 #define ARX_ATOMIC_OR(p, v) atomicOr((unsigned int *)(p), (unsigned int)(v))
 #define ARX_ATOMIC_INC(p) atomicAdd((int *)(p), 1)
+#define ARX_ATOMIC_ADD(p, v) atomicAdd((int *)(p), (int)(v))
+#define ARX_ATOMIC_MIN(p, v) atomicMin((int *)(p), (int)(v))
+#define ARX_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#define ARX_ATOMIC_MIN64(p, v) atomicMin((long long *)(p), (long long)(v))
+#define ARX_ATOMIC_MAX64(p, v) atomicMax((long long *)(p), (long long)(v))
+// plain read of a word other lanes of the workgroup update with atomics (which execute in L2): bypass the per-CU L1
+#define ARX_LOAD_SHARED(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 namespace arx {

@@ -1,6 +1,6 @@
 // dev_rfa.h -- the Go half of the per-barcode path on the device: candidate post-processing (GetChains/GetAlignments),
 // best-pair tagging, molecule inference, the RFA joint-placement sweep and the molecule-move probability sums.
-// One barcode per thread; all state of a barcode lives in its slices of batch-wide pools in HBM.
+// One barcode per workgroup; all state of a barcode lives in its slices of batch-wide pools in HBM (L2-resident while it runs).
 //
 // Reference: /root/reference/src/aligner/aligner.go -- B2 GetChains :1633, B3 GetAlignments :1484, R1 tagBestAlignments :1397,
 // R2 inferMolecules :1300 / markBestAlignmentForReadInMolecule :1340 / scrapMolecules :991, R3 scoreAlignment :556 / isPair :1032,
@@ -77,233 +77,282 @@ ARX_DEV void cand_build_read(const IndexView &ix, int read, const Reg *regs, con
 	}
 }
 
-// ---- per-barcode working view
-struct RfaView {
-	Cand *c;               // candidates of the barcode (all, filtered or not); read r owns [roff[r], roff[r+1])
-	const int32_t *roff;   // barcode-local read -> candidate offset (relative to c)
-	int n_reads, n_c, pen2;
-	int32_t *act;          // per read: its active candidate
-	// molecule tables (after scrap): groups = (molecule, read) pairs sorted by molecule then read
-	int32_t *grp_read, *grp_best, *mol_goff; // mol_goff[m]..mol_goff[m+1] = groups of molecule m
-	int32_t *mol_nact;
-	int n_mol;
+// ---- one barcode per workgroup
+//
+// The block handle B (hip_rt.h: HipBlock, 256 lanes; tests/hostsim: a sequential stand-in) provides
+//   pfor(n, f)            f(i) for every i in [0, n), lanes striding, then a workgroup barrier
+//   single(f)             lane 0 runs f, then a barrier
+//   exclusive_scan(in, out, n) -> total      (in != out)
+//   sort_kv(keys, vals, P)                   ascending by (key, (uint32)val), P a power of two
+//   argmax(n, keyf, &key, &idx)              largest keyf(i) (0 = "no candidate"), ties to the smallest i; result in every lane
+// Control flow around these calls is uniform over the workgroup: every value it depends on is read from memory after a barrier.
+// Sums that many lanes contribute to are integers (scores are half-units), so their order cannot be observed.
+struct RfaScratch {
+	int32_t *hdr;                 // [0] filtered candidates, [2..3] DNA length accumulator (int64)
+	uint64_t *skey;               // P sort keys
+	int32_t *ord;                 // P: filtered candidates in (contig first seen, position, index) order
+	int32_t *flag, *excl;         // molecule starts / scans (n_c + 2 each)
+	int32_t *spot;                // n_c: molecule a candidate is the best alignment of its read in, or -1
+	int32_t *has_active;          // n_c + 2 (pre-scrap molecules)
+	int32_t *mol_goff, *mol_nact, *cursor, *grp_read; // surviving molecules: reads with a spot in them
+	int32_t *ach, *num, *scv;     // per sink molecule accumulators of one fastScore sweep
+	int32_t *mv, *act;            // per read
+	int32_t *first_seen;          // n_seqs + 2
+	int64_t *m_lo, *m_hi, *m_len; // per molecule
+	int32_t *m_soft;
 };
-
-ARX_DEVI int rfa_best_for(const RfaView &v, int mol, int read) // molecule.best_alignment_for_read.Get(read): binary search in the molecule's groups
+ARX_HDI int rfa_pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+ARX_HDI int64_t rfa_scratch_words(int n_c, int n_reads, int n_seqs)
 {
-	int lo = v.mol_goff[mol], hi = v.mol_goff[mol + 1];
-	while (lo < hi) { int mid = (lo + hi) >> 1; if (v.grp_read[mid] < read) lo = mid + 1; else hi = mid; }
-	return (lo < v.mol_goff[mol + 1] && v.grp_read[lo] == read) ? v.grp_best[lo] : -1;
+	const int64_t P = rfa_pow2ceil(n_c), A = n_c + 2;
+	int64_t w = 16 + 2 * P + P + 12 * A + 2 * (int64_t)(n_reads + 2) + (n_seqs + 2) + 6 * A + A;
+	return (w + 3) & ~(int64_t)3;
 }
-ARX_DEVI bool rfa_mol_active(const RfaView &v, int m, int change) // isActiveMolecule
+ARX_DEVI RfaScratch rfa_carve(int32_t *scratch, int n_c, int n_reads, int n_seqs)
 {
-	const double active = (double)(v.mol_nact[m] + change), potential = (double)(v.mol_goff[m + 1] - v.mol_goff[m]);
-	if (active <= 4) return false;
-	if (active / potential < 0.1) return false;
+	const int P = rfa_pow2ceil(n_c), A = n_c + 2;
+	RfaScratch s;
+	int32_t *p = scratch;
+	s.hdr = p; p += 16;
+	s.skey = (uint64_t *)p; p += 2 * P;
+	s.m_lo = (int64_t *)p; p += 2 * A; s.m_hi = (int64_t *)p; p += 2 * A; s.m_len = (int64_t *)p; p += 2 * A;
+	s.ord = p; p += P;
+	s.flag = p; p += A; s.excl = p; p += A; s.spot = p; p += A; s.has_active = p; p += A;
+	s.mol_goff = p; p += A; s.mol_nact = p; p += A; s.cursor = p; p += A; s.grp_read = p; p += A;
+	s.ach = p; p += A; s.num = p; p += A; s.scv = p; p += A; s.m_soft = p; p += A;
+	s.mv = p; p += n_reads + 2; s.act = p; p += n_reads + 2;
+	s.first_seen = p; p += n_seqs + 2;
+	return s;
+}
+
+struct RfaView {
+	const Cand *c; const int32_t *roff; int roff0, pen2; const RfaScratch *s;
+};
+ARX_DEVI int rfa_spot_of(const RfaView &v, int read, int T) // molecule.best_alignment_for_read.Get(read): the read's own candidates are few
+{
+	for (int i = v.roff[read] - v.roff0; i < v.roff[read + 1] - v.roff0; ++i) if (v.s->spot[i] == T) return i;
+	return -1;
+}
+ARX_DEVI bool rfa_mol_active(int nact, int npot) // isActiveMolecule
+{
+	if ((double)nact <= 4) return false;
+	if ((double)nact / (double)npot < 0.1) return false;
 	return true;
 }
-
-// fastScore in half-units.  When mv_read != nullptr the (read, sink candidate) pairs acceptMove would apply are recorded.
-ARX_DEV int rfa_fast_score2(const RfaView &v, int S, int T, int *num_out, int32_t *mv_read, int32_t *mv_sink, int *n_mv)
+// fastScore's terms that do not depend on single reads (aligner.go:1200-1236), half-units
+ARX_DEVI int rfa_molecule_terms(int nact_s, int npot_s, int nact_t, int npot_t, int num)
 {
-	int change = 0, ach = 0, num = 0, nmv = 0;
-	for (int g = v.mol_goff[S]; g < v.mol_goff[S + 1]; ++g) {
-		const int read = v.grp_read[g], sa = v.act[read];
-		if (v.c[sa].mol != S) continue; // only the source's active alignments
-		const int ta = rfa_best_for(v, T, read);
-		if (ta < 0) continue;
-		const Cand &src = v.c[sa], &snk = v.c[ta];
-		const int mate = read ^ 1, sm = v.act[mate];
-		const bool source_has_mate = v.c[sm].mol == S;
-		const bool source_pair = source_has_mate && cand_is_pair(src, v.c[sm]);
-		const int tm = rfa_best_for(v, T, mate);
-		const bool sink_pair = tm >= 0 && cand_is_pair(snk, v.c[tm]) && source_has_mate;
-		if (!source_pair || (source_has_mate && sink_pair)) { if (mv_read) { mv_read[nmv] = read; mv_sink[nmv] = ta; } ++nmv; }
-		ach += snk.lap2 - src.lap2;
-		if (source_pair && !sink_pair && S != T) ach += v.pen2 / 2;
-		else if (!source_pair && sink_pair && S != T) ach -= v.pen2 / 2;
-		++num;
-	}
-	const int npot_s = v.mol_goff[S + 1] - v.mol_goff[S], npot_t = v.mol_goff[T + 1] - v.mol_goff[T];
-	if (!rfa_mol_active(v, S, -num) && rfa_mol_active(v, S, 0) && S != T) change += npot_s;
-	if (rfa_mol_active(v, T, num) && !rfa_mol_active(v, T, 0) && S != T) change -= npot_t;
-	if (v.mol_nact[S] - num == 0 && num > 0 && S != T) change += 6;
-	if (v.mol_nact[T] == 0 && num > 0 && S != T) change -= 6;
-	*num_out = num;
-	if (n_mv) *n_mv = nmv;
-	return change + ach;
+	int change = 0;
+	if (!rfa_mol_active(nact_s - num, npot_s) && rfa_mol_active(nact_s, npot_s)) change += npot_s;
+	if (rfa_mol_active(nact_t + num, npot_t) && !rfa_mol_active(nact_t, npot_t)) change -= npot_t;
+	if (nact_s - num == 0 && num > 0) change += 6;
+	if (nact_t == 0 && num > 0) change -= 6;
+	return change;
+}
+// One active read of source molecule S against its spot `ta` in sink T (the loop body of fastScore, aligner.go:1128-1198)
+ARX_DEVI int rfa_read_term(const RfaView &v, int S, int T, int read, int sa, int ta, bool *moves)
+{
+	const Cand *c = v.c;
+	const int mate = read ^ 1, sm = v.s->act[mate];
+	const bool source_has_mate = c[sm].mol == S;
+	const bool source_pair = source_has_mate && cand_is_pair(c[sa], c[sm]);
+	const int tm = rfa_spot_of(v, mate, T);
+	const bool sink_pair = tm >= 0 && cand_is_pair(c[ta], c[tm]) && source_has_mate;
+	*moves = !source_pair || (source_has_mate && sink_pair);
+	int d = c[ta].lap2 - c[sa].lap2;
+	if (source_pair && !sink_pair) d += v.pen2 / 2;
+	else if (!source_pair && sink_pair) d -= v.pen2 / 2;
+	return d;
 }
 
-struct SortByContigPos { // positions per contig in first-seen contig order, by pos, ties by candidate order (stable)
-	const Cand *c; const int32_t *first_seen; // first_seen[rid + 1] = first candidate index with that contig
-	ARX_DEVI bool operator()(int a, int b) const
-	{
-		const int fa = first_seen[c[a].rid + 1], fb = first_seen[c[b].rid + 1];
-		if (fa != fb) return fa < fb;
-		if (c[a].pos != c[b].pos) return c[a].pos < c[b].pos;
-		return a < b;
-	}
-};
-struct SortByMolRead { // (molecule, read, position rank)
-	const Cand *c; const int32_t *rank;
-	ARX_DEVI bool operator()(int a, int b) const
-	{
-		if (c[a].mol != c[b].mol) return c[a].mol < c[b].mol;
-		if (c[a].read != c[b].read) return c[a].read < c[b].read;
-		return rank[a] < rank[b];
-	}
-};
-
-// One barcode.  scratch: rfa_scratch_words(n_c, n_reads, n_seqs) int32.  p10h: table of 10^(x/2), index x + RFA_P10_HALF.
-ARX_HDI int64_t rfa_scratch_words(int n_c, int n_reads, int n_seqs) { return 7 * (int64_t)n_c + 2 + n_reads + n_seqs + 2; }
-
-ARX_DEV void rfa_barcode(Cand *c, const int32_t *roff, int n_reads, int n_c, int read0, int do_rfa, int pen_int, int n_seqs,
+template <class B>
+ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int n_c, int read0, int do_rfa, int pen_int, int n_seqs,
                          const double *p10h, int32_t *scratch, RfaBarcodeOut *out)
 {
-	RfaView v;
-	v.c = c; v.roff = roff; v.n_reads = n_reads; v.n_c = n_c; v.pen2 = 2 * pen_int; v.n_mol = 0;
-	int32_t *ord = scratch, *rank = ord + n_c, *grp_read = rank + 2 * n_c + 2, *grp_best = grp_read + n_c, *mvbuf = grp_best + n_c; // rank: 2*n_c+2 (reused for the molecule tables), mvbuf: 2*n_c
-	int32_t *act = mvbuf + 2 * n_c, *first_seen = act + n_reads;
-	v.act = act;
-	out->dna_len = 0; out->n_mol = 0;
-	// local read ids: candidates store batch-global reads; inside the barcode use read - read0
-	for (int i = 0; i < n_c; ++i) c[i].read -= read0;
-	// R1: per pair the best (candidate, mate candidate) over the filtered lists; exact ties: first pair wins
-	const int roff0 = roff[0]; // roff holds batch-global candidate offsets, c is the barcode's slice
-	for (int r = 0; r + 1 < n_reads; r += 2) {
+	const RfaScratch s = rfa_carve(scratch, n_c, n_reads, n_seqs);
+	const int roff0 = roff[0], pen2 = 2 * pen_int; // roff holds batch-global candidate offsets, c is the barcode's slice
+	RfaView v; v.c = c; v.roff = roff; v.roff0 = roff0; v.pen2 = pen2; v.s = &s;
+	int32_t *act = s.act;
+	// R1 tagBestAlignments: per pair the best (candidate, mate candidate) over the filtered lists; exact ties: first pair wins
+	blk.pfor(n_reads / 2, [&](int pr) {
+		const int r = 2 * pr;
 		int bs = 0, ba = -1, bm = -1;
 		for (int i = roff[r] - roff0; i < roff[r + 1] - roff0; ++i) {
 			if (!c[i].in_filtered) continue;
 			for (int j = roff[r + 1] - roff0; j < roff[r + 2] - roff0; ++j) {
 				if (!c[j].in_filtered) continue;
-				const int s = cand_pair_score2(c[i], c[j], v.pen2);
-				if (ba < 0 || s > bs) { bs = s; ba = i; bm = j; }
+				const int sc = cand_pair_score2(c[i], c[j], pen2);
+				if (ba < 0 || sc > bs) { bs = sc; ba = i; bm = j; }
 			}
 		}
 		c[ba].active = 1; c[bm].active = 1;
 		if (cand_is_pair(c[ba], c[bm])) { c[ba].is_proper = 1; c[bm].is_proper = 1; }
 		act[r] = ba; act[r + 1] = bm;
-	}
-	if (do_rfa) {
-		// R2 inferMolecules: filtered candidates, contigs in first-seen order, sorted by position, split at gaps > 50 kb
-		for (int s = 0; s < n_seqs + 1; ++s) first_seen[s] = 0x7fffffff;
-		int m_c = 0;
-		for (int i = 0; i < n_c; ++i) if (c[i].in_filtered) { ord[m_c++] = i; if (first_seen[c[i].rid + 1] > i) first_seen[c[i].rid + 1] = i; }
-		SortByContigPos lt1; lt1.c = c; lt1.first_seen = first_seen;
-		ks_introsort(m_c, ord, lt1);
-		int n_mol0 = 0;
-		for (int t = 0; t < m_c; ++t) {
-			const int i = ord[t];
-			if (t == 0 || c[ord[t - 1]].rid != c[i].rid || c[i].pos - c[ord[t - 1]].pos > 50000) ++n_mol0;
-			c[i].mol = n_mol0 - 1;
-			rank[i] = t;
-		}
-		// markBestAlignmentForReadInMolecule: group by (molecule, read); the best candidate of a group against the mate's group
-		SortByMolRead lt2; lt2.c = c; lt2.rank = rank;
-		ks_introsort(m_c, ord, lt2);
-		// has_active per pre-scrap molecule, kept in mvbuf[0..n_mol0)
-		int32_t *has_active = mvbuf;
-		for (int m = 0; m < n_mol0; ++m) has_active[m] = 0;
-		for (int t = 0; t < m_c;) {
-			const int m = c[ord[t]].mol, r = c[ord[t]].read;
-			int e = t;
-			while (e < m_c && c[ord[e]].mol == m && c[ord[e]].read == r) ++e;
-			// mate group: same molecule, read r^1 -- adjacent to this group in the sorted order
-			int ms = -1, me = -1;
-			if ((r & 1) == 0) { if (e < m_c && c[ord[e]].mol == m && c[ord[e]].read == r + 1) { ms = e; me = e; while (me < m_c && c[ord[me]].mol == m && c[ord[me]].read == r + 1) ++me; } }
-			else { int b0 = t; while (b0 > 0 && c[ord[b0 - 1]].mol == m && c[ord[b0 - 1]].read == r - 1) --b0; if (b0 < t) { ms = b0; me = t; } }
+	});
+	if (!do_rfa) { blk.single([&]() { out->dna_len = 0; out->n_mol = 0; }); return; }
+
+	// R2 inferMolecules: filtered candidates, contigs in first-seen order, sorted by position, split at gaps > 50 kb
+	const int P = rfa_pow2ceil(n_c);
+	blk.pfor(n_seqs + 2 > 16 ? n_seqs + 2 : 16, [&](int q) { if (q < n_seqs + 2) s.first_seen[q] = 0x7fffffff; if (q < 16) s.hdr[q] = 0; });
+	blk.pfor(n_c, [&](int i) { s.spot[i] = -1; if (c[i].in_filtered) { ARX_ATOMIC_MIN(&s.first_seen[c[i].rid + 1], i); ARX_ATOMIC_INC(&s.hdr[0]); } });
+	blk.pfor(P, [&](int i) {
+		const bool f = i < n_c && c[i].in_filtered;
+		s.ord[i] = i < n_c ? i : -1;
+		s.skey[i] = f ? ((uint64_t)ARX_LOAD_SHARED(&s.first_seen[c[i].rid + 1]) << 36) | (uint64_t)(c[i].pos + 1) : ~(uint64_t)0;
+	});
+	blk.sort_kv(s.skey, s.ord, P);
+	const int m_c = ARX_LOAD_SHARED(&s.hdr[0]);
+	blk.pfor(m_c, [&](int t) {
+		const int i = s.ord[t];
+		s.flag[t] = t == 0 || c[s.ord[t - 1]].rid != c[i].rid || c[i].pos - c[s.ord[t - 1]].pos > 50000;
+	});
+	const int n_mol0 = blk.exclusive_scan(s.flag, s.excl, m_c);
+	blk.pfor(m_c > n_mol0 ? m_c : n_mol0, [&](int t) {
+		if (t < m_c) c[s.ord[t]].mol = s.excl[t] + s.flag[t] - 1;
+		if (t < n_mol0) s.has_active[t] = 0;
+	});
+	// markBestAlignmentForReadInMolecule: per (molecule, read) group the candidate that scores best against the mate's
+	// group in the same molecule (alone: by its own probability); ties go to the smaller position rank = index in ord,
+	// which for two candidates of one group is the order of (position, candidate index)
+	blk.pfor(n_reads, [&](int r) {
+		const int lo = roff[r] - roff0, hi = roff[r + 1] - roff0, mlo = roff[r ^ 1] - roff0, mhi = roff[(r ^ 1) + 1] - roff0;
+		for (int i = lo; i < hi; ++i) {
+			if (!c[i].in_filtered) continue;
+			const int m = c[i].mol;
+			if (c[i].active) s.has_active[m] = 1;
+			bool leader = true;
+			for (int k = lo; k < i; ++k) if (c[k].in_filtered && c[k].mol == m) { leader = false; break; }
+			if (!leader) continue;
 			int best = -1, bs = 0;
-			for (int a = t; a < e; ++a) {
-				const int ia = ord[a];
-				if (ms >= 0) {
-					for (int b = ms; b < me; ++b) { const int s = cand_pair_score2(c[ia], c[ord[b]], v.pen2); if (best < 0 || s > bs) { bs = s; best = ia; } }
-				} else if (best < 0 || c[ia].lap2 > bs) { bs = c[ia].lap2; best = ia; }
-				if (c[ia].active) has_active[m] = 1;
+			for (int a = i; a < hi; ++a) {
+				if (!c[a].in_filtered || c[a].mol != m) continue;
+				int val = c[a].lap2; bool any = false;
+				for (int b = mlo; b < mhi; ++b) {
+					if (!c[b].in_filtered || c[b].mol != m) continue;
+					const int sc = cand_pair_score2(c[a], c[b], pen2);
+					if (!any || sc > val) { val = sc; any = true; }
+				}
+				const bool before = best >= 0 && (c[a].pos < c[best].pos); // a > best in index, so it ranks first only on a smaller position
+				if (best < 0 || val > bs || (val == bs && before)) { bs = val; best = a; }
 			}
 			c[best].best_in_mol = 1;
-			t = e;
 		}
-		// scrapMolecules: renumber molecules that hold an active alignment; the others disappear
-		int cnt = 0;
-		for (int m = 0; m < n_mol0; ++m) has_active[m] = has_active[m] ? cnt++ : -1;
-		for (int t = 0; t < m_c; ++t) { Cand &x = c[ord[t]]; x.mol = has_active[x.mol]; if (x.mol < 0) x.best_in_mol = 0; }
-		// group tables of the surviving molecules (ord is still sorted by old molecule id; renumbering keeps the order)
-		int32_t *mol_goff = rank;           // rank[] is free now: reuse for mol_goff (cnt + 1 entries) and mol_nact (cnt entries)
-		int32_t *mol_nact = rank + cnt + 1;
-		int n_g = 0, cur_m = -1;
-		for (int t = 0; t < m_c; ++t) {
-			const Cand &x = c[ord[t]];
-			if (x.mol < 0 || !x.best_in_mol) continue;
-			while (cur_m < x.mol) mol_goff[++cur_m] = n_g;
-			grp_read[n_g] = x.read; grp_best[n_g] = ord[t]; ++n_g;
+	});
+	// scrapMolecules: molecules holding an active alignment are renumbered in order; the others disappear
+	const int cnt = blk.exclusive_scan(s.has_active, s.excl, n_mol0);
+	blk.pfor(m_c > cnt + 1 ? m_c : cnt + 1, [&](int t) {
+		if (t < m_c) {
+			Cand &x = c[s.ord[t]];
+			x.mol = s.has_active[x.mol] ? s.excl[x.mol] : -1;
+			if (x.mol < 0) x.best_in_mol = 0;
+			s.spot[s.ord[t]] = x.best_in_mol ? x.mol : -1;
 		}
-		while (cur_m < cnt) mol_goff[++cur_m] = n_g;
-		for (int m = 0; m < cnt; ++m) mol_nact[m] = 0;
-		for (int r = 0; r < n_reads; ++r) if (c[act[r]].mol >= 0) ++mol_nact[c[act[r]].mol];
-		v.grp_read = grp_read; v.grp_best = grp_best; v.mol_goff = mol_goff; v.mol_nact = mol_nact; v.n_mol = cnt;
-		// R5 Optimize(obj, 1, 2, 4*M): two sweeps of 4*M greedy moves, sources round robin
-		if (cnt > 0) {
-			int32_t *mvr = mvbuf, *mvs = mvbuf + n_c; // candidate moves of the sink being scored (<= n_reads <= n_c entries each)
-			int cur = 0;
-			for (int it = 0; it < 8 * cnt; ++it) {
-				const int S = cur;
-				cur = (cur + 1) % cnt;
-				if (mol_nact[S] == 0) continue;
-				int have = 0, best_sc = 0, best_T = -1;
-				for (int T = 0; T < cnt; ++T) {
-					if (T == S) continue;
-					int num, sc = rfa_fast_score2(v, S, T, &num, 0, 0, 0);
-					if (num > 0 && (!have || sc > best_sc || (sc == best_sc && mol_nact[T] > mol_nact[best_T]))) { have = 1; best_sc = sc; best_T = T; }
-				}
-				if (have && (best_sc > 0 || (best_sc == 0 && mol_nact[best_T] > mol_nact[S]))) {
-					int num, nmv;
-					rfa_fast_score2(v, S, best_T, &num, mvr, mvs, &nmv); // recompute the winning move's read list, then acceptMove
-					for (int q = 0; q < nmv; ++q) {
-						const int read = mvr[q];
-						c[act[read]].active = 0; --mol_nact[S];
-						c[mvs[q]].active = 1; ++mol_nact[best_T];
-						act[read] = mvs[q];
-					}
-				}
+		if (t <= cnt) { s.cursor[t] = 0; s.mol_nact[t] = 0; }
+	});
+	blk.pfor(n_c > n_reads ? n_c : n_reads, [&](int i) {
+		if (i < n_c && s.spot[i] >= 0) ARX_ATOMIC_INC(&s.cursor[s.spot[i]]);
+		if (i < n_reads && c[act[i]].mol >= 0) ARX_ATOMIC_INC(&s.mol_nact[c[act[i]].mol]);
+	});
+	blk.pfor(cnt + 1, [&](int m) { s.flag[m] = m < cnt ? ARX_LOAD_SHARED(&s.cursor[m]) : 0; });
+	blk.exclusive_scan(s.flag, s.mol_goff, cnt + 1); // mol_goff[cnt] = number of (molecule, read) spots
+	blk.pfor(cnt, [&](int m) { s.cursor[m] = s.mol_goff[m]; });
+	blk.pfor(n_c, [&](int i) { if (s.spot[i] >= 0) s.grp_read[ARX_ATOMIC_ADD(&s.cursor[s.spot[i]], 1)] = c[i].read - read0; });
+
+	// one sweep of fastScore(S, *) over the active reads of S: ach/num per sink molecule
+	auto sweep = [&](int S) {
+		blk.pfor(cnt, [&](int T) { s.ach[T] = 0; s.num[T] = 0; });
+		blk.pfor(s.mol_goff[S + 1] - s.mol_goff[S], [&](int g) {
+			const int read = s.grp_read[s.mol_goff[S] + g], sa = act[read];
+			if (c[sa].mol != S) return;
+			for (int ta = roff[read] - roff0; ta < roff[read + 1] - roff0; ++ta) {
+				const int T = s.spot[ta];
+				if (T < 0 || T == S) continue;
+				bool moves;
+				const int d = rfa_read_term(v, S, T, read, sa, ta, &moves);
+				ARX_ATOMIC_ADD(&s.ach[T], d); ARX_ATOMIC_INC(&s.num[T]);
 			}
-		}
-		// R6 method 2: sum_move += 10^fastScore(S, T) for every active alignment of S that has a spot in T
-		for (int S = 0; S < cnt; ++S)
-			for (int T = 0; T < cnt; ++T) {
-				if (S == T) continue;
-				int num, sc = rfa_fast_score2(v, S, T, &num, 0, 0, 0);
-				const double p = sc < -RFA_P10_HALF ? p10h[0] * 0.0 : (sc > RFA_P10_HALF ? p10h[2 * RFA_P10_HALF] * 1e300 * 1e300 : p10h[sc + RFA_P10_HALF]);
-				for (int g = mol_goff[S]; g < mol_goff[S + 1]; ++g) {
-					const int read = grp_read[g], sa = act[read];
-					if (c[sa].mol == S && rfa_best_for(v, T, read) >= 0) c[sa].sum_move += p;
-				}
-			}
-		// setMoleculeConfidences + updateAlignmentsMoleculeStatus + the DNA length of calculateLogMoleculePenalty
-		double dna = 1000.0;
-		for (int m = 0; m < cnt; ++m) {
-			const int npot = mol_goff[m + 1] - mol_goff[m];
-			int soft = 0;
-			int64_t lo = 0x7fffffffffffffffLL, hi = -1;
-			double inactive_len = 0.0;
-			for (int g = mol_goff[m]; g < mol_goff[m + 1]; ++g) {
-				const Cand &a = c[act[grp_read[g]]];
-				if (a.mol != m) continue;
-				if (a.soft_clipped > 0) ++soft;
-				if (a.pos > hi) hi = a.pos;
-				if (a.pos < lo) lo = a.pos;
-				inactive_len += (double)(a.aend - a.pos) * 2.0;
-			}
-			const double conf = (double)mol_nact[m] / (double)npot;
-			const bool is_act = mol_nact[m] - soft > 4 && conf > 0.1;
-			if (is_act) { if (hi >= lo) dna += (double)(hi - lo) + 1000.0; }
-			else dna += inactive_len;
-			mol_nact[m] = is_act ? -1 - mol_nact[m] : mol_nact[m]; // flag in the sign; no score is computed after this point
-		}
-		for (int t = 0; t < m_c; ++t) { Cand &x = c[ord[t]]; if (x.mol >= 0) x.active_molecule = mol_nact[x.mol] < 0; }
-		out->dna_len = cnt > 0 ? dna : 0.0;
-		out->n_mol = cnt;
+		});
+	};
+	auto score_of = [&](int S, int T, int num) {
+		return rfa_molecule_terms(ARX_LOAD_SHARED(&s.mol_nact[S]), s.mol_goff[S + 1] - s.mol_goff[S], ARX_LOAD_SHARED(&s.mol_nact[T]),
+		                          s.mol_goff[T + 1] - s.mol_goff[T], num) + ARX_LOAD_SHARED(&s.ach[T]);
+	};
+	// R5 Optimize(obj, 1, 2, 4*M): two sweeps of 4*M greedy moves, sources round robin.  The walk is deterministic, so once
+	// M consecutive sources in a row changed nothing the remaining iterations cannot change anything either.
+	int idle = 0;
+	for (int it = 0; it < 8 * cnt && idle < cnt; ++it) {
+		const int S = it % cnt;
+		const int nact_s = ARX_LOAD_SHARED(&s.mol_nact[S]);
+		if (nact_s == 0) { ++idle; continue; }
+		sweep(S);
+		uint64_t bkey; int best_T;
+		blk.argmax(cnt, [&](int T) -> uint64_t {
+			const int num = ARX_LOAD_SHARED(&s.num[T]);
+			if (T == S || num == 0) return 0;
+			return ((uint64_t)(uint32_t)(score_of(S, T, num) + 0x40000000) << 32) | (uint32_t)ARX_LOAD_SHARED(&s.mol_nact[T]);
+		}, &bkey, &best_T);
+		const int best_sc = (int)(uint32_t)(bkey >> 32) - 0x40000000;
+		if (bkey == 0 || !(best_sc > 0 || (best_sc == 0 && (int)(uint32_t)bkey > nact_s))) { ++idle; continue; }
+		idle = 0;
+		const int g0 = s.mol_goff[S], ng = s.mol_goff[S + 1] - g0, T = best_T;
+		blk.pfor(ng, [&](int g) { // acceptMove works from the state before the move: decide every read first ...
+			const int read = s.grp_read[g0 + g], sa = act[read];
+			s.mv[read] = -1;
+			if (c[sa].mol != S) return;
+			const int ta = rfa_spot_of(v, read, T);
+			if (ta < 0) return;
+			bool moves;
+			rfa_read_term(v, S, T, read, sa, ta, &moves);
+			if (moves) s.mv[read] = ta;
+		});
+		blk.pfor(ng, [&](int g) { // ... then apply
+			const int read = s.grp_read[g0 + g], ta = s.mv[read];
+			if (ta < 0) return;
+			c[act[read]].active = 0; c[ta].active = 1; act[read] = ta;
+			ARX_ATOMIC_ADD(&s.mol_nact[S], -1); ARX_ATOMIC_INC(&s.mol_nact[T]);
+		});
 	}
-	for (int i = 0; i < n_c; ++i) c[i].read += read0;
+	// R6 method 2: sum_move += 10^fastScore(S, T), T ascending, for every active alignment of S that has a spot in T
+	for (int S = 0; S < cnt; ++S) {
+		if (ARX_LOAD_SHARED(&s.mol_nact[S]) == 0) continue;
+		sweep(S);
+		blk.pfor(cnt, [&](int T) { const int num = ARX_LOAD_SHARED(&s.num[T]); s.scv[T] = (T != S && num > 0) ? score_of(S, T, num) : 0; });
+		blk.pfor(s.mol_goff[S + 1] - s.mol_goff[S], [&](int g) {
+			const int read = s.grp_read[s.mol_goff[S] + g], sa = act[read];
+			if (c[sa].mol != S) return;
+			double sum = c[sa].sum_move;
+			for (int last = -1;;) { // the read's other spots in ascending molecule order
+				int T = 0x7fffffff;
+				for (int i = roff[read] - roff0; i < roff[read + 1] - roff0; ++i) { const int m = s.spot[i]; if (m > last && m != S && m < T) T = m; }
+				if (T == 0x7fffffff) break;
+				const int sc = s.scv[T];
+				sum += sc < -RFA_P10_HALF ? p10h[0] * 0.0 : (sc > RFA_P10_HALF ? p10h[2 * RFA_P10_HALF] * 1e300 * 1e300 : p10h[sc + RFA_P10_HALF]);
+				last = T;
+			}
+			c[sa].sum_move = sum;
+		});
+	}
+	// setMoleculeConfidences + updateAlignmentsMoleculeStatus + the DNA length of calculateLogMoleculePenalty (all terms are integers)
+	blk.pfor(cnt, [&](int m) { s.m_soft[m] = 0; s.m_lo[m] = 0x7fffffffffffffffLL; s.m_hi[m] = -1; s.m_len[m] = 0; });
+	blk.pfor(n_reads, [&](int r) {
+		const Cand &a = c[act[r]];
+		const int m = a.mol;
+		if (m < 0) return;
+		if (a.soft_clipped > 0) ARX_ATOMIC_INC(&s.m_soft[m]);
+		ARX_ATOMIC_MAX64(&s.m_hi[m], a.pos); ARX_ATOMIC_MIN64(&s.m_lo[m], a.pos);
+		ARX_ATOMIC_ADD64(&s.m_len[m], (a.aend - a.pos) * 2);
+	});
+	int64_t *dna = (int64_t *)(s.hdr + 2);
+	blk.pfor(cnt, [&](int m) {
+		const int npot = s.mol_goff[m + 1] - s.mol_goff[m], nact = ARX_LOAD_SHARED(&s.mol_nact[m]);
+		const int64_t lo = ARX_LOAD_SHARED(&s.m_lo[m]), hi = ARX_LOAD_SHARED(&s.m_hi[m]);
+		const bool is_act = nact - ARX_LOAD_SHARED(&s.m_soft[m]) > 4 && (double)nact / (double)npot > 0.1;
+		s.flag[m] = is_act;
+		if (is_act) { if (hi >= lo) ARX_ATOMIC_ADD64(dna, (hi - lo) + 1000); }
+		else ARX_ATOMIC_ADD64(dna, ARX_LOAD_SHARED(&s.m_len[m]));
+	});
+	blk.pfor(m_c, [&](int t) { Cand &x = c[s.ord[t]]; if (x.mol >= 0) x.active_molecule = s.flag[x.mol]; });
+	blk.single([&]() { out->dna_len = cnt > 0 ? 1000.0 + (double)ARX_LOAD_SHARED(dna) : 0.0; out->n_mol = cnt; });
 }
 
 } // namespace arx

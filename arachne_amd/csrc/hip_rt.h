@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "hip_sw_coop.h"
+#include "hip_block.h"
 #include "hip_fm_coop.h"
 
 namespace arx {
@@ -163,6 +164,15 @@ struct HipRT {
 		Scope sc(*this, nm, n);
 		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
 		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	// one work item per 256-lane workgroup (hip_block.h); f(item, HipBlock&)
+	template <class F> void launch_block(const char *nm, int n, const F &f)
+	{
+		if (n <= 0) return;
+		Scope sc(*this, nm, n);
+		int blocks = n < n_cu * 8 ? n : n_cu * 8;
+		hipLaunchKernelGGL(k_block_items<F>, dim3(blocks), dim3(BLOCK_LANES), 0, stream, f, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void launch_small(const char *nm, int n, const F &f)

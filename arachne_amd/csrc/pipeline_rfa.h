@@ -17,13 +17,13 @@ struct KCandBuild {
 	IndexView ix; const int32_t *preg_off, *n_regs, *cand_off; const Reg *pregs; const Aln *alns; const uint32_t *cig; int cig_w; Cand *cands;
 	ARX_DEV void operator()(int r, int) const { cand_build_read(ix, r, pregs, alns, cig, cig_w, preg_off[r], n_regs[r], cands + cand_off[r]); }
 };
-struct KRfa { // one barcode per thread
+struct KRfa { // one barcode per workgroup
 	const int32_t *cand_off; const int32_t *bc_read_off; const uint8_t *do_rfa; const int64_t *scr_off; int pen_int, n_seqs;
 	const double *p10h; Cand *cands; int32_t *scratch; RfaBarcodeOut *out;
-	ARX_DEV void operator()(int b, int) const
+	template <class B> ARX_DEV void operator()(int b, B &blk) const
 	{
 		const int r0 = bc_read_off[b], r1 = bc_read_off[b + 1];
-		rfa_barcode(cands + cand_off[r0], cand_off + r0, r1 - r0, cand_off[r1] - cand_off[r0], r0, do_rfa[b], pen_int, n_seqs, p10h, scratch + scr_off[b], out + b);
+		rfa_barcode(blk, cands + cand_off[r0], cand_off + r0, r1 - r0, cand_off[r1] - cand_off[r0], r0, do_rfa[b], pen_int, n_seqs, p10h, scratch + scr_off[b], out + b);
 	}
 };
 
@@ -67,7 +67,7 @@ template <class RT> struct RfaStage {
 		rt.h2d(d_bro, bro.data(), 4 * (size_t)(n_barcodes + 1)); rt.h2d(d_so, so.data(), 8 * (size_t)(n_barcodes + 1));
 		rt.h2d(d_flags, do_rfa, n_barcodes); rt.h2d(d_p10, p10.data(), 8 * p10.size());
 		KRfa kr{cand_off, d_bro, d_flags, d_so, penalty, pipe.ix.n_seqs, d_p10, cands, d_scr, d_out};
-		rt.launch("rfa", n_barcodes, kr);
+		rt.launch_block("rfa", n_barcodes, kr);
 		res.cands.resize((size_t)NC); res.bc.resize(n_barcodes);
 		rt.d2h(res.cands.data(), cands, sizeof(Cand) * (size_t)NC);
 		rt.d2h(res.bc.data(), d_out, sizeof(RfaBarcodeOut) * (size_t)n_barcodes);

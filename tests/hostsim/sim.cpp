@@ -17,9 +17,47 @@
 #define ARX_HDI inline
 #define ARX_ATOMIC_OR(p, v) (*(p) |= (v))
 #define ARX_ATOMIC_INC(p) ((*(p))++)
+#define ARX_ATOMIC_ADD(p, v) sim_fetch_add((p), (v))
+#define ARX_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define ARX_ATOMIC_ADD64(p, v) (*(p) += (v))
+#define ARX_ATOMIC_MIN64(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define ARX_ATOMIC_MAX64(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
+#define ARX_LOAD_SHARED(p) (*(p))
+static inline int sim_fetch_add(int32_t *p, int v) { int o = *p; *p += v; return o; }
 #include "../../arachne_amd/csrc/arx_dev.h"
 
+#include <algorithm>
 namespace arx {
+// sequential stand-in for hip_block.h's HipBlock: one "lane" runs every parallel-for in index order
+// (ARX_SIM_PFOR=1: descending, =2: a stride permutation -- a phase whose result depends on the lane order is a race on the GPU)
+struct SimBlock {
+	int order = getenv("ARX_SIM_PFOR") ? atoi(getenv("ARX_SIM_PFOR")) : 0;
+	template <class F> void pfor(int n, F f)
+	{
+		if (order == 1) { for (int i = n - 1; i >= 0; --i) f(i); return; }
+		if (order == 2 && n > 2) { // i -> (i * step) mod n with gcd(step, n) = 1
+			int64_t step = 7919; while (std::__gcd<int64_t>(step, n) != 1) ++step;
+			for (int64_t i = 0; i < n; ++i) f((int)((i * step + 3) % n));
+			return;
+		}
+		for (int i = 0; i < n; ++i) f(i);
+	}
+	template <class F> void single(F f) { f(); }
+	int exclusive_scan(const int32_t *in, int32_t *out, int n) { int t = 0; for (int i = 0; i < n; ++i) { int x = in[i]; out[i] = t; t += x; } out[n] = t; return t; }
+	void sort_kv(uint64_t *k, int32_t *v, int P)
+	{
+		std::vector<std::pair<std::pair<uint64_t, uint32_t>, int> > a(P);
+		for (int i = 0; i < P; ++i) a[i] = std::make_pair(std::make_pair(k[i], (uint32_t)v[i]), i);
+		std::sort(a.begin(), a.end());
+		for (int i = 0; i < P; ++i) { k[i] = a[i].first.first; v[i] = (int32_t)a[i].first.second; }
+	}
+	template <class F> void argmax(int n, F keyf, uint64_t *key, int *idx)
+	{
+		uint64_t bk = 0; int bi = 0x7fffffff;
+		for (int i = 0; i < n; ++i) { uint64_t x = keyf(i); if (x > bk) { bk = x; bi = i; } }
+		*key = bk; *idx = bi;
+	}
+};
 struct KernelTimer { double ms = 0; int64_t calls = 0, items = 0; };
 struct SimRT {
 	static const char *name() { return "hostsim"; }
@@ -45,6 +83,7 @@ struct SimRT {
 	void timers_reset(bool) { tm.clear(); }
 	template <class F> void launch(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; for (int i = 0; i < n; ++i) f(i, 0); }
 	template <class F> void launch_small(const char *nm, int n, const F &f) { launch(nm, n, f); }
+	template <class F> void launch_block(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; SimBlock blk; for (int i = 0; i < n; ++i) f(i, blk); }
 	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
 	template <class F> void run_locate(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }

@@ -164,9 +164,11 @@ def _device_vs_oracle(lib_path, seed):
     ref.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2])
-def test_device_logic_matches_restatement_hostsim(seed):
+@pytest.mark.parametrize("seed,lane_order", [(1, 0), (2, 0), (2, 1), (1, 2), (2, 2)])
+def test_device_logic_matches_restatement_hostsim(seed, lane_order, monkeypatch):
+    """lane_order != 0 runs every workgroup-parallel phase of the RFA code in another lane order: the result may not depend on it."""
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    monkeypatch.setenv("ARX_SIM_PFOR", str(lane_order))
     _device_vs_oracle(SIM, seed)
 
 
