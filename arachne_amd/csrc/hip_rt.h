@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include "hip_sw_coop.h"
 #include "hip_block.h"
 #include "hip_fm_coop.h"
@@ -136,9 +137,11 @@ struct HipRT {
 	{
 		if (pending.empty()) return;
 		(void)hipStreamSynchronize(stream);
+		static FILE *launch_log = getenv("ARX_LAUNCH_LOG") ? fopen(getenv("ARX_LAUNCH_LOG"), "a") : nullptr; // diagnostics: one line per launch
 		for (auto &p : pending) {
 			float ms = 0;
 			(void)hipEventElapsedTime(&ms, p.a, p.b);
+			if (launch_log) fprintf(launch_log, "%s\t%lld\t%.4f\n", p.nm, (long long)p.items, ms);
 			KernelTimer &t = tm[p.nm]; t.ms += ms; ++t.calls; t.items += p.items;
 			free_events.push_back(p.a); free_events.push_back(p.b);
 		}
