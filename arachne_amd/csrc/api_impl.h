@@ -198,13 +198,14 @@ template <class RT> struct Batch {
 		ARX_TRY(c, b->rt.bind(); b->rt.set_timing(c->timing);                                                                       \
 			if (b->rfa_marked) b->rt.arena_rewind(b->rfa_mark); else { b->rfa_mark = b->rt.arena_mark(); b->rfa_marked = true; }    \
 			arx::RfaStage<RT>::run(b->pipe, b->db, b->work, n_barcodes, bc_pair_off, do_rfa, penalty, cen_start, cen_end, b->lens_host.data(), b->rfa); \
-			*n_cands = (int64_t)b->rfa.cands.size();)                                                                               \
+			*n_cands = b->rfa.n_cands;)                                                                               \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_rfa_fetch(arx_ctx *h, arx_batch *bh, int32_t *cand_off, arx_cand *cands)                                          \
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
-		if (b->rfa.cand_off.empty()) { c->set_error("arx_batch_rfa_fetch before arx_batch_rfa"); return ARX_E_ARG; }                \
+		if (b->rfa.cand_off.empty() || !b->rfa_marked) { c->set_error("arx_batch_rfa_fetch before arx_batch_rfa"); return ARX_E_ARG; } \
+		ARX_TRY(c, b->rt.bind(); arx::RfaStage<RT>::fetch(b->pipe, b->db, b->work, b->rfa);)                                        \
 		static_assert(sizeof(arx_cand) == sizeof(arx::Cand), "C-ABI structs must mirror the device structs");                       \
 		memcpy(cand_off, b->rfa.cand_off.data(), 4 * b->rfa.cand_off.size());                                                       \
 		memcpy(cands, b->rfa.cands.data(), sizeof(arx::Cand) * b->rfa.cands.size());                                                \

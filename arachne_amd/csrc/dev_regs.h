@@ -296,11 +296,19 @@ ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, R
 // Mate rescue: GoBwaMemMateSW's two loops (/root/reference/src/gobwa/gobwa.go:285-324) around mem_matesw
 // (bwamem_pair.c:111-180) with the fixed insert model (only FR valid, [-35, 500]).
 // ------------------------------------------------------------------------------------------------
+// The SW of one (anchor, mate) rescue depends only on the anchor region and the mate's sequence; what depends on earlier
+// rescues of the same loop is whether it is skipped (a mate region already sits in the window) and how its result is merged.
+// So each loop is run in two steps: every SW the loop could need, given the mate list as it stands when the loop starts, is
+// queued at once (rescue_enumerate) and computed in one launch; then the loop is replayed in order with the results at hand.
+// A rescue can only add skips, except when the merge drops the region that caused one; the replay then asks for that
+// single SW the slow way (phase 1) -- rare, but it keeps the result exactly the sequential one.
 struct ResState {
 	int64_t rb, re;        // clamped window of the pending SW
-	int32_t e, i, num, n_snap, best[2], phase, pad;
+	uint64_t spec_mask;    // bit k: the k-th anchor above the score threshold had its SW queued ahead
+	int32_t e, i, num, n_snap, best[2], phase, spec_off; // phase 0: replaying, 1: waiting for a single SW, 2: finished, 3: loop `e` not enumerated yet
 };
-struct SwTask { int64_t rb, re; int32_t pair, o; };
+struct SwTask { int64_t rb, re; int32_t pair, o, slot, pad; };
+struct SwEmit { SwTask *tasks; int32_t *n_tasks, *n_slots; int32_t single_slot, no_ahead; }; // no_ahead (tests): queue nothing ahead, every SW takes the single path; n_tasks: this round's queue; n_slots: result slots handed out so far (they live until the stage ends); single_slot: this pair's phase-1 result
 
 ARX_DEVI int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) // mem_infer_dir (bwamem_pair.c:23-31)
 {
@@ -337,45 +345,94 @@ ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Re
 	return sort_dedup_patch(ix, 0, n_ma, ma, tmp, idx, 0);
 }
 
-// Advance one pair until it needs a SW (true) or both rescue loops are finished (false).
-// regs[e]/n_regs[e]: the two reads' region lists (with spare capacity).
-ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *const regs[2], int *n_regs[2], Reg *const tmp[2], int *const idx[2],
-                         ResState &st, const U8Res &res, SwTask &task)
+// Window of the FR rescue of anchor `a` (bwamem_pair.c:126-133 with r = 1: mate reversed, larger coordinate)
+ARX_DEVI bool rescue_window(const IndexView &ix, const Reg &a, int l_ms, int64_t *prb, int64_t *pre)
+{
+	int64_t rb = a.rb + PES_LOW - l_ms, re = a.rb + PES_HIGH;
+	int rid = -1;
+	if (rb < 0) rb = 0;
+	if (re > ix.l_pac << 1) re = ix.l_pac << 1;
+	if (rb < re) fetch_clamp(ix, &rb, (rb + re) >> 1, &re, &rid);
+	*prb = rb; *pre = re;
+	return a.rid == rid && re - rb >= OPT_MIN_SEED_LEN;
+}
+ARX_DEVI bool rescue_skipped(const IndexView &ix, const Reg &a, const Reg *ma, int n_ma) // bwamem_pair.c:118-124
+{
+	for (int j = 0; j < n_ma; ++j) {
+		int64_t dist;
+		int r = infer_dir(ix.l_pac, a.rb, ma[j].rb, &dist);
+		if (r == 1 && dist >= PES_LOW && dist <= PES_HIGH) return true;
+	}
+	return false;
+}
+
+// Every SW loop st.e would run against the mate list as it is now.  out == nullptr: count only.
+ARX_DEV int rescue_enumerate(const IndexView &ix, int pair, const int *lens2, Reg *const regs[2], int *const n_regs[2], const ResState &st, uint64_t *mask,
+                             SwTask *out, int slot0)
+{
+	const int e = st.e, o = 1 - e, l_ms = lens2[o];
+	int num = 0, cnt = 0;
+	*mask = 0;
+	if (l_ms <= 0) return 0;
+	for (int i = 0; i < st.n_snap && num < MAX_RESCUE; ++i) {
+		const Reg a = regs[e][i];
+		if (a.score < st.best[e] - 25) continue;
+		const int k = num++;
+		if (rescue_skipped(ix, a, regs[o], *n_regs[o])) continue;
+		int64_t rb, re;
+		if (!rescue_window(ix, a, l_ms, &rb, &re)) continue;
+		*mask |= (uint64_t)1 << k;
+		if (out) { SwTask t; t.rb = rb; t.re = re; t.pair = pair; t.o = o; t.slot = slot0 + cnt; t.pad = 0; out[cnt] = t; }
+		++cnt;
+	}
+	return cnt;
+}
+
+// Advance one pair until it has queued SWs whose results it needs (true) or both rescue loops are finished (false).
+// regs[e]/n_regs[e]: the two reads' region lists (with spare capacity); sres: SW results by slot.
+ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *const regs[2], int *const n_regs[2], Reg *const tmp[2], int *const idx[2],
+                         ResState &st, const U8Res *sres, const SwEmit &emit)
 {
 	for (;;) {
 		if (st.phase == 2) return false;
+		if (st.phase == 3) { // start of a loop: queue its SWs
+			uint64_t mask;
+			int cnt = emit.no_ahead ? 0 : rescue_enumerate(ix, pair, lens2, regs, n_regs, st, &mask, nullptr, 0);
+			if (emit.no_ahead) mask = 0;
+			st.spec_mask = mask; st.spec_off = 0; st.i = 0; st.num = 0; st.phase = 0;
+			if (cnt > 0) {
+				st.spec_off = ARX_ATOMIC_ADD(emit.n_slots, cnt);
+				rescue_enumerate(ix, pair, lens2, regs, n_regs, st, &mask, emit.tasks + ARX_ATOMIC_ADD(emit.n_tasks, cnt), st.spec_off);
+				return true;
+			}
+		}
 		const int e = st.e, o = 1 - e;
-		if (st.phase == 1) { // a SW came back: ma = the other read's list
-			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], res, st.rb, regs[o], *n_regs[o], tmp[o], idx[o]);
+		if (st.phase == 1) { // the single SW came back: ma = the other read's list
+			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], sres[emit.single_slot], st.rb, regs[o], *n_regs[o], tmp[o], idx[o]);
 			st.phase = 0; ++st.i;
 		}
 		if (st.i >= st.n_snap || st.num >= MAX_RESCUE || lens2[o] <= 0) {
-			if (e == 1) { st.e = 0; st.i = 0; st.num = 0; st.n_snap = *n_regs[0]; continue; } // second loop walks the POST-rescue read-1 list
+			if (e == 1) { st.e = 0; st.n_snap = *n_regs[0]; st.phase = 3; continue; } // second loop walks the POST-rescue read-1 list
 			st.phase = 2;
 			return false;
 		}
 		const Reg a = regs[e][st.i];
 		if (a.score < st.best[e] - 25) { ++st.i; continue; } // threshold stays the PRE-rescue best (gobwa.go:302-312)
-		++st.num;
-		bool skip = false; // an existing mate region already sits in the FR window (bwamem_pair.c:118-124)
-		for (int j = 0; j < *n_regs[o]; ++j) {
-			int64_t dist;
-			int r = infer_dir(ix.l_pac, a.rb, regs[o][j].rb, &dist);
-			if (r == 1 && dist >= PES_LOW && dist <= PES_HIGH) { skip = true; break; }
+		const int k = st.num++;
+		if (rescue_skipped(ix, a, regs[o], *n_regs[o])) { ++st.i; continue; }
+		int64_t rb, re;
+		if (!rescue_window(ix, a, lens2[o], &rb, &re)) { ++st.i; continue; } // nothing aligned: ma stays as it is
+		if (st.spec_mask >> k & 1) {
+			const int slot = st.spec_off + __builtin_popcountll(st.spec_mask & (((uint64_t)1 << k) - 1));
+			*n_regs[o] = matesw_apply(ix, a, lens2[o], sres[slot], rb, regs[o], *n_regs[o], tmp[o], idx[o]);
+			++st.i;
+			continue;
 		}
-		if (skip) { ++st.i; continue; }
-		const int l_ms = lens2[o];
-		int64_t rb = a.rb + PES_LOW - l_ms, re = a.rb + PES_HIGH; // r = 1: mate reversed, larger coordinate
-		int rid = -1;
-		if (rb < 0) rb = 0;
-		if (re > ix.l_pac << 1) re = ix.l_pac << 1;
-		if (rb < re) fetch_clamp(ix, &rb, (rb + re) >> 1, &re, &rid);
-		if (a.rid == rid && re - rb >= OPT_MIN_SEED_LEN) {
-			st.rb = rb; st.re = re; st.phase = 1;
-			task.rb = rb; task.re = re; task.pair = pair; task.o = o;
-			return true;
-		}
-		++st.i; // nothing aligned: ma stays as it is
+		st.rb = rb; st.re = re; st.phase = 1;
+		SwTask t; t.rb = rb; t.re = re; t.pair = pair; t.o = o; t.slot = emit.single_slot; t.pad = 0;
+		emit.tasks[ARX_ATOMIC_ADD(emit.n_tasks, 1)] = t;
+		ARX_ATOMIC_INC(emit.n_slots + 1); // statistics: SWs that could not be queued ahead
+		return true;
 	}
 }
 

@@ -12,6 +12,7 @@
 // final MAPQ; api_impl.h).  Rules that replace Go-runtime behaviour the reference leaves unpinned (tie jitter, unstable
 // sort of equal positions) are the ones stated in oracle/arx_oracle_rfa.c, which this code must match bit for bit.
 #pragma once
+#include <math.h>
 #include "arx_dev.h"
 
 namespace arx {
@@ -75,6 +76,71 @@ ARX_DEV void cand_build_read(const IndexView &ix, int read, const Reg *regs, con
 		c.in_filtered = rg.score >= best - 17;
 		out[i] = c;
 	}
+}
+
+// ---- estimateMapQualities' floating-point tail for one read (aligner.go:797-922): method 1 normalises the read's pair
+// scores over the 15 largest (plus the pseudo-count of an unseen placement), method 2 comes from sum_move; min, cap at 60.
+// Compiled for both sides: the device evaluates it for every read with its own pow/log10; where the value is so close to
+// an integer that a few ulp could change int(mapq), the host re-evaluates it with libm (pipeline_rfa.h), so that the
+// result is the host-libm one everywhere.  Returns the value before the centromere mask and the int conversion.
+ARX_HDI void rfa_top15_push(double *top, int &nt, double v) // keeps the 15 largest, largest first
+{
+	int at = nt;
+	while (at > 0 && top[at - 1] < v) --at;
+	if (at >= 15) return;
+	const int last = nt < 15 ? nt : 14;
+	for (int k = last; k > at; --k) top[k] = top[k - 1];
+	top[at] = v;
+	if (nt < 15) ++nt;
+}
+ARX_HDI double rfa_mapq_value(const Cand *c, int r_lo, int r_hi, int m_lo, int m_hi, int len_r, double log_mol_pen, int penalty, int *a_out, double *largest)
+{
+	const double pen = (double)penalty, NEG = -1.7976931348623157e308;
+	const int pen2 = 2 * penalty;
+	double top[15];
+	int nt = 0, a = -1, am = -1;
+	double best_single = NEG;
+	for (int j = m_lo; j < m_hi; ++j) {
+		if (!c[j].in_filtered) continue;
+		const double s = 0.5 * c[j].lap2 + pen;
+		if (s > best_single) best_single = s;
+	}
+	const double pseudo = -10.0 - ((double)len_r - 25.0) * 0.5 + log_mol_pen;
+	rfa_top15_push(top, nt, best_single + pseudo);
+	for (int i = r_lo; i < r_hi; ++i) {
+		if (!c[i].in_filtered) continue;
+		if (c[i].active) a = i;
+		double bs = NEG;
+		for (int j = m_lo; j < m_hi; ++j) {
+			if (!c[j].in_filtered) continue;
+			if (c[j].active) am = j;
+			const double s = 0.5 * cand_pair_score2(c[i], c[j], pen2) + (c[i].active_molecule ? 0.0 : log_mol_pen);
+			if (s > bs) bs = s;
+		}
+		rfa_top15_push(top, nt, bs);
+	}
+	double total = 0.0;
+	for (int x = 0; x < nt; ++x) total += pow(10.0, top[x]);
+	const double sc = 0.5 * cand_pair_score2(c[a], c[am], pen2) + (c[a].active_molecule ? 0.0 : log_mol_pen);
+	double mapq = -10.0 * log10(1.0 - pow(10.0, sc) / total);
+	const double mmq = -10.0 * log10(1.0 - (1.0 / c[a].sum_move));
+	mapq = (mapq != mapq || mmq != mmq) ? mapq + mmq : (mapq < mmq ? mapq : mmq); // NaN stays NaN
+	*a_out = a; *largest = top[0];
+	return mapq;
+}
+constexpr double RFA_MAPQ_GUARD = 1e-6; // |value - nearest integer| below this goes to the host; device/libm differences are < 1e-8 for values <= 60
+ARX_HDI bool rfa_mapq_needs_host(double v, double largest, double guard)
+{
+	if (v != v || largest < -290.0) return true;       // NaN, or 10^x near the underflow range
+	if (v > 60.0 + guard) return false;                // capped
+	const double f = v - floor(v);
+	return f < guard || f > 1.0 - guard;
+}
+ARX_HDI int rfa_mapq_final(double v, const Cand &a, const int64_t *cen_start, const int64_t *cen_end)
+{
+	double mapq = (v != v) ? v : (v < 60.0 ? v : 60.0);
+	if (cen_start && a.rid >= 0 && a.pos > cen_start[a.rid] && a.pos <= cen_end[a.rid]) mapq = 0.0;
+	return (mapq != mapq) ? (int)0x80000000 : (int)mapq;
 }
 
 // ---- one barcode per workgroup

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
 	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
 		const SwTask t = tasks[i];
 		const int r = 2 * t.pair + t.o;
-		sw_u8_align_g16<SL>(ix, bases + base_off[r], lens[r], t.rb, (int)(t.re - t.rb), rowmax_lds[g], &res[t.pair]);
+		sw_u8_align_g16<SL>(ix, bases + base_off[r], lens[r], t.rb, (int)(t.re - t.rb), rowmax_lds[g], &res[t.slot]);
 	}
 }
 

@@ -146,13 +146,15 @@ struct KPairInit {
 			for (int i = 0; i < n; ++i) { Reg x = regs[occ_off[r] + i]; pregs[preg_off[r] + i] = x; if (x.score > best) best = x.score; }
 			n_regs[r] = n; st.best[e] = best;
 		}
-		st.e = 1; st.i = 0; st.num = 0; st.n_snap = n_core[2 * p + 1]; st.phase = 0; // first loop: anchors = read 2's hits
+		st.e = 1; st.i = 0; st.num = 0; st.n_snap = n_core[2 * p + 1]; st.phase = 3; // first loop: anchors = read 2's hits
 		state[p] = st;
 	}
 };
 
 struct KRescueStep {
-	IndexView ix; const int32_t *lens, *preg_off; Reg *pregs, *ptmp; int32_t *pidx, *n_regs; ResState *state; const U8Res *res; SwTask *tasks; int32_t *n_tasks;
+	IndexView ix; const int32_t *lens, *preg_off; Reg *pregs, *ptmp; int32_t *pidx, *n_regs; ResState *state; const U8Res *res; SwTask *tasks; int32_t *n_tasks, *n_slots;
+	int32_t no_ahead;
+	int32_t single_base; // result slots [0, single_base): SWs queued ahead; single_base + pair: the pair's single SW
 	ARX_DEV void operator()(int p, int) const
 	{
 		ResState st = state[p];
@@ -161,10 +163,9 @@ struct KRescueStep {
 		Reg *tm[2] = { ptmp + preg_off[2 * p], ptmp + preg_off[2 * p + 1] };
 		int *ix2[2] = { pidx + preg_off[2 * p], pidx + preg_off[2 * p + 1] };
 		int *nr[2] = { n_regs + 2 * p, n_regs + 2 * p + 1 };
-		SwTask t;
-		bool more = rescue_step(ix, p, lens + 2 * p, rg, nr, tm, ix2, st, res[p], t);
+		SwEmit em; em.tasks = tasks; em.n_tasks = n_tasks; em.n_slots = n_slots; em.single_slot = single_base + p; em.no_ahead = no_ahead;
+		rescue_step(ix, p, lens + 2 * p, rg, nr, tm, ix2, st, res, em);
 		state[p] = st;
-		if (more) tasks[KExtStep::claim(n_tasks)] = t;
 	}
 };
 
@@ -178,7 +179,7 @@ struct KSwU8 {
 		const uint8_t *ms = bases + base_off[r];
 		for (int k = 0; k < l_ms; ++k) { int b = ms[k]; qbuf[l_ms - 1 - k] = b < 4 ? 3 - b : 4; } // reverse complement of the mate (bwamem_pair.c:134-137)
 		for (int k = 0; k < tlen; ++k) tbuf[k] = (uint8_t)ref_base(ix, t.rb + k);
-		res[t.pair] = u8_align(qbuf, l_ms, tbuf, tlen, KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A), row, stride, rowmax);
+		res[t.slot] = u8_align(qbuf, l_ms, tbuf, tlen, KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A), row, stride, rowmax);
 	}
 };
 
@@ -347,18 +348,24 @@ public:
 		w.P = rt.exclusive_scan(w.cap, w.preg_off, R);
 		const size_t P = (size_t)w.P + 1;
 		w.pregs = rt.template alloc<Reg>(P); w.ptmp = rt.template alloc<Reg>(P); w.pidx = rt.template alloc<int32_t>(P);
-		w.rst = rt.template alloc<ResState>(NP + 1); w.stask = rt.template alloc<SwTask>(NP + 1); w.sres = rt.template alloc<U8Res>(NP + 1);
+		// a loop queues at most min(n_regs, MAX_RESCUE) SWs per pair, so both loops stay below 2P result slots; plus one single SW per pair
+		w.rst = rt.template alloc<ResState>(NP + 1); w.stask = rt.template alloc<SwTask>(P + NP + 1); w.sres = rt.template alloc<U8Res>(2 * P + NP + 1);
+		int32_t *n_slots = rt.template alloc<int32_t>(2); // [0] result slots handed out, [1] single SWs
+		rt.memset0(n_slots, 8);
 		const int q_cap = (b.max_len + 15) & ~15, t_cap = (PES_HIGH - PES_LOW + 2 * b.max_len + 31) & ~15;
 		w.sw_scr = rt.template alloc<uint8_t>((size_t)slots * (q_cap + 2 * t_cap));
 		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst};
 		rt.launch("pair_init", NP, ki);
 		for (int round = 0;; ++round) {
 			rt.memset0(w.counter, 4);
-			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter};
+			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter, n_slots, getenv("ARX_RESCUE_NO_AHEAD") ? 1 : 0, (int32_t)(2 * w.P)};
 			rt.launch_cold("rescue_step", NP, ks);
 			int nt = read_counter(w);
 			if (trace) { fprintf(stderr, "[arx] rescue round %d: %d tasks\n", round, nt); fflush(stderr); }
-			if (nt == 0) break;
+			if (nt == 0) {
+				if (trace) { int32_t ns[2]; rt.d2h(ns, n_slots, 8); fprintf(stderr, "[arx] rescue: %d SWs queued ahead, %d single\n", ns[0], ns[1]); fflush(stderr); }
+				break;
+			}
 			if (round > 2 * MAX_RESCUE + 4) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; }
 			out.n_sw_tasks += nt; ++out.rescue_rounds;
 			KSwU8 kw{ix, b.bases, b.base_off, b.lens, w.stask, w.sres, w.sw_scr, q_cap, t_cap};

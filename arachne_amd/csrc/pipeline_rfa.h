@@ -3,6 +3,8 @@
 // estimateMapQualities on the device; the floating-point tail of estimateMapQualities (aligner.go:797-922) on the host.
 #pragma once
 #include <cmath>
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "pipeline.h"
 #include "dev_rfa.h"
@@ -27,7 +29,26 @@ struct KRfa { // one barcode per workgroup
 	}
 };
 
-struct RfaResult { std::vector<int32_t> cand_off; std::vector<Cand> cands; std::vector<RfaBarcodeOut> bc; };
+struct KMapq { // one read per lane: MAPQ of its active candidate; values a few ulp could change are queued for the host
+	Cand *cands; const int32_t *cand_off; const int32_t *lens; const int32_t *bc_read_off; int n_barcodes; const double *log_mol_pen;
+	int penalty; const int64_t *cen_start, *cen_end; double guard; int32_t *flagged, *n_flagged;
+	ARX_DEV void operator()(int r, int) const
+	{
+		int lo = 0, hi = n_barcodes;
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bc_read_off[mid] <= r) lo = mid; else hi = mid; }
+		const int mr = r ^ 1;
+		int a; double largest;
+		const double v = rfa_mapq_value(cands, cand_off[r], cand_off[r + 1], cand_off[mr], cand_off[mr + 1], lens[r], log_mol_pen[lo], penalty, &a, &largest);
+		cands[a].mapq = rfa_mapq_final(v, cands[a], cen_start, cen_end); // the mate's lane reads other fields of this record, never mapq
+		if (rfa_mapq_needs_host(v, largest, guard)) flagged[ARX_ATOMIC_INC(n_flagged)] = r;
+	}
+};
+struct KMapqPatch { Cand *cands; const int32_t *idx, *val; ARX_DEV void operator()(int k, int) const { cands[idx[k]].mapq = val[k]; } };
+
+struct RfaResult {
+	std::vector<int32_t> cand_off; std::vector<Cand> cands; std::vector<RfaBarcodeOut> bc;
+	Cand *d_cands = nullptr; int64_t n_cands = 0; bool fetched = false; int64_t n_host_mapq = 0;
+};
 
 template <class RT> struct RfaStage {
 	// bc_pair_off[n_barcodes + 1]: pair offsets of whole barcodes inside the batch; do_rfa[b] = worthRunningRFA (aligner.go:1018-1030)
@@ -68,71 +89,72 @@ template <class RT> struct RfaStage {
 		rt.h2d(d_flags, do_rfa, n_barcodes); rt.h2d(d_p10, p10.data(), 8 * p10.size());
 		KRfa kr{cand_off, d_bro, d_flags, d_so, penalty, pipe.ix.n_seqs, d_p10, cands, d_scr, d_out};
 		rt.launch_block("rfa", n_barcodes, kr);
-		res.cands.resize((size_t)NC); res.bc.resize(n_barcodes);
-		rt.d2h(res.cands.data(), cands, sizeof(Cand) * (size_t)NC);
+		res.bc.resize(n_barcodes);
 		rt.d2h(res.bc.data(), d_out, sizeof(RfaBarcodeOut) * (size_t)n_barcodes);
-		{ // `reg` leaves the device as a slot of the (capacity-sized) region pool; callers index the compact arrays of arx_batch_fetch
-			std::vector<int32_t> po(R + 1), nr(R);
-			rt.d2h(po.data(), w.preg_off, 4 * (size_t)(R + 1)); rt.d2h(nr.data(), w.n_regs, 4 * (size_t)R);
-			int32_t compact = 0;
-			for (int r = 0; r < R; ++r) {
-				for (int i = res.cand_off[r]; i < res.cand_off[r + 1]; ++i) if (res.cands[i].reg >= 0) res.cands[i].reg = compact + (res.cands[i].reg - po[r]);
-				compact += nr[r];
-			}
+		// calculateLogMoleculePenalty (aligner.go:722-741) with libm on the host: one log10 per barcode
+		std::vector<double> lmp(n_barcodes);
+		for (int i = 0; i < n_barcodes; ++i) lmp[i] = (do_rfa[i] && res.bc[i].n_mol > 0) ? std::log10(res.bc[i].dna_len / 3200000000.0 * 0.05) : 0.0;
+		double *d_lmp = rt.template alloc<double>(n_barcodes + 1);
+		rt.h2d(d_lmp, lmp.data(), 8 * (size_t)n_barcodes);
+		const int n_seqs = pipe.ix.n_seqs;
+		int64_t *d_cs = nullptr, *d_ce = nullptr;
+		if (cen_start && cen_end) {
+			d_cs = rt.template alloc<int64_t>(n_seqs + 1); d_ce = rt.template alloc<int64_t>(n_seqs + 1);
+			rt.h2d(d_cs, cen_start, 8 * (size_t)n_seqs); rt.h2d(d_ce, cen_end, 8 * (size_t)n_seqs);
 		}
-		finalize_mapq(res, bro, do_rfa, penalty, cen_start, cen_end, lens_host);
+		int32_t *d_flag = rt.template alloc<int32_t>(R + 1);
+		rt.memset0(w.counter, 4);
+		const char *ge = getenv("ARX_MAPQ_GUARD"); // tests widen the guard to push every read through the host path
+		const double guard = ge ? atof(ge) : RFA_MAPQ_GUARD;
+		KMapq km{cands, cand_off, b.lens, d_bro, n_barcodes, d_lmp, penalty, d_cs, d_ce, guard, d_flag, w.counter};
+		rt.launch("mapq", R, km);
+		const int nf = pipe.read_counter(w);
+		res.n_host_mapq = nf;
+		if (nf > 0) host_mapq(rt, nf, d_flag, cands, res, bro, lmp, penalty, cen_start, cen_end, lens_host);
+		res.d_cands = cands; res.n_cands = NC; res.fetched = false; res.cands.clear();
 		return 0;
 	}
 
-	// estimateMapQualities' floating-point tail (aligner.go:825-918): method-1 normalisation over the top 15 pair scores,
-	// method 2 from sum_move, min, cap at 60, centromere mask, int().  Same operations in the same order as the oracle.
-	static void finalize_mapq(RfaResult &res, const std::vector<int32_t> &bro, const uint8_t *do_rfa, int penalty,
-	                          const int64_t *cen_start, const int64_t *cen_end, const int32_t *lens)
+	// the reads KMapq queued: same evaluation with the host's libm on their (pair's) candidate records, patched into HBM
+	static void host_mapq(RT &rt, int nf, const int32_t *d_flag, Cand *cands, const RfaResult &res, const std::vector<int32_t> &bro, const std::vector<double> &lmp,
+	                      int penalty, const int64_t *cen_start, const int64_t *cen_end, const int32_t *lens)
 	{
-		const double pen = (double)penalty;
-		const int pen2 = 2 * penalty;
-		std::vector<double> scores;
-		for (size_t bi = 0; bi + 1 < bro.size(); ++bi) {
-			const RfaBarcodeOut &bo = res.bc[bi];
-			const double log_mol_pen = (do_rfa[bi] && bo.n_mol > 0) ? std::log10(bo.dna_len / 3200000000.0 * 0.05) : 0.0;
-			for (int r = bro[bi]; r < bro[bi + 1]; ++r) {
-				const int mr = r ^ 1;
-				const Cand *c = res.cands.data();
-				scores.clear();
-				double best_single = -1.7976931348623157e308;
-				for (int j = res.cand_off[mr]; j < res.cand_off[mr + 1]; ++j) {
-					if (!c[j].in_filtered) continue;
-					const double s = 0.5 * c[j].lap2 + pen;
-					if (s > best_single) best_single = s;
-				}
-				const double pseudo = -10.0 - ((double)lens[r] - 25.0) * 0.5 + log_mol_pen;
-				scores.push_back(best_single + pseudo);
-				int a = -1, am = -1;
-				for (int i = res.cand_off[r]; i < res.cand_off[r + 1]; ++i) {
-					if (!c[i].in_filtered) continue;
-					if (c[i].active) a = i;
-					double bs = -1.7976931348623157e308;
-					for (int j = res.cand_off[mr]; j < res.cand_off[mr + 1]; ++j) {
-						if (!c[j].in_filtered) continue;
-						if (c[j].active) am = j;
-						const double s = 0.5 * cand_pair_score2(c[i], c[j], pen2) + (c[i].active_molecule ? 0.0 : log_mol_pen);
-						if (s > bs) bs = s;
-					}
-					scores.push_back(bs);
-				}
-				for (size_t x = 1; x < scores.size(); ++x) { double t = scores[x]; size_t y = x; while (y > 0 && scores[y - 1] > t) { scores[y] = scores[y - 1]; --y; } scores[y] = t; }
-				double total = 0.0;
-				const int ns = (int)scores.size();
-				for (int x = ns - 1; x >= 0 && ns - x <= 15; --x) total += std::pow(10.0, scores[x]);
-				const double sc = 0.5 * cand_pair_score2(c[a], c[am], pen2) + (c[a].active_molecule ? 0.0 : log_mol_pen);
-				double mapq = -10.0 * std::log10(1.0 - std::pow(10.0, sc) / total);
-				const double mmq = -10.0 * std::log10(1.0 - (1.0 / c[a].sum_move));
-				mapq = (mapq != mapq || mmq != mmq) ? NAN : (mapq < mmq ? mapq : mmq);
-				mapq = (mapq != mapq) ? NAN : (mapq < 60.0 ? mapq : 60.0);
-				if (cen_start && c[a].rid >= 0 && c[a].pos > cen_start[c[a].rid] && c[a].pos <= cen_end[c[a].rid]) mapq = 0.0;
-				res.cands[a].mapq = (mapq != mapq) ? (int)0x80000000 : (int)mapq;
-			}
+		std::vector<int32_t> fl(nf), pidx(nf), pval(nf);
+		rt.d2h(fl.data(), d_flag, 4 * (size_t)nf);
+		std::vector<Cand> buf;
+		for (int k = 0; k < nf; ++k) {
+			const int r = fl[k], p0 = r & ~1, base = res.cand_off[p0], n = res.cand_off[p0 + 2] - base;
+			buf.resize(n);
+			rt.d2h(buf.data(), cands + base, sizeof(Cand) * (size_t)n);
+			const int bi = (int)(std::upper_bound(bro.begin(), bro.end(), r) - bro.begin()) - 1, mr = r ^ 1;
+			int a; double largest;
+			const double v = rfa_mapq_value(buf.data(), res.cand_off[r] - base, res.cand_off[r + 1] - base, res.cand_off[mr] - base, res.cand_off[mr + 1] - base,
+			                                lens[r], lmp[bi], penalty, &a, &largest);
+			pidx[k] = base + a; pval[k] = rfa_mapq_final(v, buf[a], cen_start, cen_end);
 		}
+		int32_t *d_i = rt.template alloc<int32_t>(nf), *d_v = rt.template alloc<int32_t>(nf);
+		rt.h2d(d_i, pidx.data(), 4 * (size_t)nf); rt.h2d(d_v, pval.data(), 4 * (size_t)nf);
+		KMapqPatch kp{cands, d_i, d_v};
+		rt.launch("mapq_patch", nf, kp);
+	}
+
+	// candidate records to the host (arx_batch_rfa_fetch); `reg` leaves the device as a slot of the (capacity-sized)
+	// region pool, callers index the compact arrays of arx_batch_fetch
+	static void fetch(Pipeline<RT> &pipe, const typename Pipeline<RT>::DeviceBatch &b, typename Pipeline<RT>::Work &w, RfaResult &res)
+	{
+		if (res.fetched) return;
+		RT &rt = pipe.rt;
+		const int R = b.n_reads;
+		res.cands.resize((size_t)res.n_cands);
+		rt.d2h(res.cands.data(), res.d_cands, sizeof(Cand) * (size_t)res.n_cands);
+		std::vector<int32_t> po(R + 1), nr(R);
+		rt.d2h(po.data(), w.preg_off, 4 * (size_t)(R + 1)); rt.d2h(nr.data(), w.n_regs, 4 * (size_t)R);
+		int32_t compact = 0;
+		for (int r = 0; r < R; ++r) {
+			for (int i = res.cand_off[r]; i < res.cand_off[r + 1]; ++i) if (res.cands[i].reg >= 0) res.cands[i].reg = compact + (res.cands[i].reg - po[r]);
+			compact += nr[r];
+		}
+		res.fetched = true;
 	}
 };
 

@@ -46,6 +46,16 @@ def test_pair_path_against_golden(env):
     parity.check_final(dev, gold)
 
 
+def test_rescue_single_sw_path(env, monkeypatch):
+    """Mate rescue normally computes every SW of a loop in one launch and replays the loop; a SW that could not be queued
+    ahead takes the one-at-a-time path.  ARX_RESCUE_NO_AHEAD=1 sends every SW down that path."""
+    z, ref, o = env
+    monkeypatch.setenv("ARX_RESCUE_NO_AHEAD", "1")
+    dev = ref.mem_mate_sw(z["reads"], z["lens"])
+    gold = dict(reg_off=z["pair_reg_off"], regs=z["pair_regs"], alns=z["pair_alns"], cigars=z["pair_cigars"])
+    parity.check_final(dev, gold)
+
+
 def test_ragged_and_degenerate_reads(env):
     z, ref, o = env
     rows = [z["reads"][i] for i in range(40)]

@@ -172,7 +172,17 @@ def test_device_logic_matches_restatement_hostsim(seed, lane_order, monkeypatch)
     _device_vs_oracle(SIM, seed)
 
 
+def test_host_mapq_path_hostsim(monkeypatch):
+    """ARX_MAPQ_GUARD=0.6 sends every read through the host re-evaluation + patch path (normally a handful per batch)."""
+    monkeypatch.setenv("ARX_MAPQ_GUARD", "0.6")
+    _device_vs_oracle(SIM, 2)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [3, 4])
-def test_gpu_matches_restatement(seed):
+@pytest.mark.parametrize("seed,guard", [(3, None), (4, None), (4, "0.6")])
+def test_gpu_matches_restatement(seed, guard, monkeypatch):
+    """MAPQ comes from the device's pow/log10 except within the guard band of an integer, where the host's libm decides;
+    guard=0.6 forces the host path for every read."""
+    if guard:
+        monkeypatch.setenv("ARX_MAPQ_GUARD", guard)
     _device_vs_oracle(api.LIB_PATH, seed)
