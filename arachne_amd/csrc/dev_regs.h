@@ -447,6 +447,34 @@ ARX_DEVI int infer_bw(int l1, int l2, int score, int a, int q, int r) // bwamem.
 	return w;
 }
 
+// Band mem_reg2aln starts from (bwamem.c:1098-1103), and the bytes of traceback matrix its widest retry can need
+ARX_DEVI int reg2aln_w0(const Reg &ar)
+{
+	const int l1 = ar.qe - ar.qb, l2 = (int)(ar.re - ar.rb);
+	int tmp = infer_bw(l1, l2, ar.truesc, OPT_A, OPT_O_DEL, OPT_E_DEL);
+	int w2 = infer_bw(l1, l2, ar.truesc, OPT_A, OPT_O_INS, OPT_E_INS);
+	w2 = w2 > tmp ? w2 : tmp;
+	if (w2 > OPT_W) w2 = w2 < ar.w ? w2 : ar.w;
+	return w2;
+}
+ARX_DEVI int64_t reg2aln_z_bound(const Reg &ar)
+{
+	const int l1 = ar.qe - ar.qb, l2 = (int)(ar.re - ar.rb);
+	if (l1 <= 0 || l2 <= 0) return 0;
+	int w_ = reg2aln_w0(ar);
+	w_ = w_ < 0 ? 0 : w_;
+	w_ = (w_ << 2) < (OPT_W << 2) ? (w_ << 2) : (OPT_W << 2); // at most two doublings, capped (bwamem.c:1104-1113)
+	int max_gap = ((l1 + 1) >> 1) - 5;
+	max_gap = max_gap > 1 ? max_gap : 1;
+	int w = (max_gap + iabs(l2 - l1) + 1) >> 1;
+	w = w < w_ ? w : w_;
+	const int min_w = iabs(l2 - l1) + 3;
+	w = w > min_w ? w : min_w;
+	const int n_col = l1 < 2 * w + 1 ? l1 : 2 * w + 1;
+	return (int64_t)n_col * l2;
+}
+constexpr int NW_Q_CAP = 256, NW_T_CAP = 1024; // what the 16-lane CIGAR kernel stages per region; larger regions take the one-thread path
+
 // cg: cap words of output CIGAR for this region; returns false when cap is too small (caller retries with a larger slot)
 ARX_DEV bool reg2aln(const IndexView &ix, int l_query, const uint8_t *query, const Reg &ar, int32_t *eh, uint8_t *z, uint32_t *cg, int cap, Aln &a)
 {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include "hip_sw_coop.h"
 #include "hip_block.h"
+#include "hip_nw_coop.h"
 #include "hip_fm_coop.h"
 
 namespace arx {
@@ -218,6 +219,17 @@ struct HipRT {
 		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
 		if (max_len <= 159) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, f.res, n);
 		else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, f.res, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	// CIGARs of the gapped regions: 16 lanes per region (hip_nw_coop.h); f is pipeline.h's KReg2Aln
+	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *zbuf, const int32_t *z_off)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch_small(nm, n, f); return; }
+		Scope sc(*this, nm, n);
+		NwArgs A{f.ix, f.bases, f.base_off, f.lens, f.preg_off, f.n_regs, f.n_reads, f.pregs, f.alns, f.cig, f.cig_w, zbuf, z_off, f.nw_list, f.err};
+		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
+		hipLaunchKernelGGL(k_reg2aln_nw_g16, dim3(blocks), dim3(64), 0, stream, A, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words_per_thread)

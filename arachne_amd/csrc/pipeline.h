@@ -187,9 +187,10 @@ struct KReg2Aln {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *preg_off, *n_regs; int n_reads; const Reg *pregs;
 	Aln *alns; uint32_t *cig; int cig_w; int32_t *eh; int eh_words; uint8_t *z; int z_cap; uint32_t *err;
 	int32_t *nw_list, *nw_count; int mode; // mode 0: every region slot, gap-free ones finished inline, the rest queued; mode 1: the queued ones
+	int32_t *nw_need, *big_list; // per queued region: 64-byte units of traceback matrix; regions too long for the 16-lane kernel (nw_count[1] of them)
 	ARX_DEV void operator()(int item, int slot) const
 	{
-		const int g = mode ? nw_list[item] : item;
+		const int g = mode == 2 ? big_list[item] : (mode ? nw_list[item] : item);
 		int lo = 0, hi = n_reads;
 		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (preg_off[mid] <= g) lo = mid; else hi = mid; }
 		const int r = lo, j = g - preg_off[r];
@@ -202,7 +203,12 @@ struct KReg2Aln {
 			// both infer_bw() calls give 0 <=> equal lengths and fewer than 12 score units lost: the CIGAR is one M run (bwa.c:141-149)
 			const int l1 = ar.qe - ar.qb, l2 = (int)(ar.re - ar.rb);
 			const bool gapfree = l1 == l2 && l1 * OPT_A - ar.truesc < ((OPT_O_DEL + OPT_E_DEL - OPT_A) << 1);
-			if (!gapfree) { nw_list[KExtStep::claim(nw_count)] = g; return; }
+			if (!gapfree) {
+				if (l1 > NW_Q_CAP || l2 > NW_T_CAP) { big_list[KExtStep::claim(nw_count + 1)] = g; return; }
+				const int k = KExtStep::claim(nw_count);
+				nw_list[k] = g; nw_need[k] = (int32_t)((reg2aln_z_bound(ar) + 63) >> 6);
+				return;
+			}
 			if (!reg2aln(ix, lq, bases + base_off[r], ar, (int32_t *)0, (uint8_t *)0, cig + (size_t)g * cig_w, cig_w, a)) KSeed::atomic_or_err(err, ERR_CIGAR_OVERFLOW);
 			alns[g] = a;
 			return;
@@ -384,16 +390,25 @@ public:
 		rt.free(w.eh); w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
 		w.alns = rt.template alloc<Aln>(P);
 		w.nw_list = rt.template alloc<int32_t>(P);
+		int32_t *nw_need = rt.template alloc<int32_t>(P + 1), *nw_zoff = rt.template alloc<int32_t>(P + 2), *big_list = rt.template alloc<int32_t>(P);
+		int32_t *cnt2 = rt.template alloc<int32_t>(2);
 		for (w.cig_w = 16;; w.cig_w *= 2) {
 			if (w.cig) rt.free(w.cig);
 			w.cig = rt.template alloc<uint32_t>(P * w.cig_w);
-			rt.memset0(w.counter, 4);
+			rt.memset0(cnt2, 8);
 			KReg2Aln k{ix, b.bases, b.base_off, b.lens, w.preg_off, w.n_regs, b.n_reads, w.pregs, w.alns, w.cig, w.cig_w, w.eh, eh_words, w.z, z_cap, w.err,
-			           w.nw_list, w.counter, 0};
+			           w.nw_list, cnt2, 0, nw_need, big_list};
 			rt.launch("reg2aln", (int)w.P, k);
-			const int n_nw = read_counter(w);
-			k.mode = 1;
-			rt.launch_small("reg2aln_nw", n_nw, k);
+			int32_t n2[2];
+			rt.d2h(n2, cnt2, 8);
+			if (n2[0] > 0) { // gapped regions: every one gets its own slice of traceback matrix, sized from its band
+				const int64_t units = rt.exclusive_scan(nw_need, nw_zoff, n2[0]);
+				uint8_t *zbuf = rt.template alloc<uint8_t>((size_t)units * 64 + 64);
+				k.mode = 1;
+				rt.run_reg2aln_nw("reg2aln_nw", n2[0], k, zbuf, nw_zoff);
+			}
+			k.mode = 2;
+			rt.launch_small("reg2aln_nw_big", n2[1], k);
 			uint32_t e = read_err(w);
 			if (!(e & ERR_CIGAR_OVERFLOW)) return (int)e;
 			if (w.cig_w >= 1024) return (int)e;

@@ -88,6 +88,7 @@ struct SimRT {
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
 	template <class F> void run_locate(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
 	template <class F> void run_extend(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, max_len + 1); }
+	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *, const int32_t *) { launch(nm, n, f); }
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words)
 	{
 		std::vector<uint32_t> row(words + 8);
