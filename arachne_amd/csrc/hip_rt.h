@@ -147,6 +147,7 @@ struct HipRT {
 			free_events.push_back(p.a); free_events.push_back(p.b);
 		}
 		pending.clear();
+		if (launch_log) fflush(launch_log);
 	}
 	std::map<std::string, KernelTimer> &timers() { resolve_timers(); return tm; }
 	void timers_reset(bool enable) { resolve_timers(); tm.clear(); timing = enable; }

@@ -59,16 +59,16 @@ __device__ __forceinline__ uint32_t u8_score_word(int tb)
 
 struct SwSeqs { // how the two passes read their sequences without materialising them
 	const uint8_t *mate; int l_ms;   // forward mate; the query is its reverse complement (bwamem_pair.c:134-137)
-	int64_t rb;                      // doubled coordinate of target[0]
+	const uint8_t *tl;               // the target window, staged in LDS once per alignment (both passes read it)
 	int q_rev, t_rev;                // second pass: the first q_rev / t_rev elements are read back to front (ksw.c:357)
 	__device__ __forceinline__ int q0(int k) const { int b = mate[l_ms - 1 - k]; return b < 4 ? 3 - b : 4; }
 	__device__ __forceinline__ int q(int k) const { return q0(k < q_rev ? q_rev - 1 - k : k); }
-	__device__ __forceinline__ int t(const IndexView &ix, int i) const { return ref_base(ix, rb + (i < t_rev ? t_rev - 1 - i : i)); }
+	__device__ __forceinline__ int t(int i) const { return tl[i < t_rev ? t_rev - 1 - i : i]; }
 };
 
 // one ksw_u8 pass by a 16-lane group; every lane returns the same U8Res (score2/te2 only valid in lane 0 of the group)
 template <int SL>
-__device__ U8Res sw_u8_pass_g16(const IndexView &ix, const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
+__device__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
 {
 	const int l = __lane_id() & 15;
 	const int slen = (qlen + 15) >> 4;
@@ -82,7 +82,7 @@ __device__ U8Res sw_u8_pass_g16(const IndexView &ix, const SwSeqs &sq, int qlen,
 	}
 	int gmax = 0, te = -1, hlast = 0, rows = 0;
 	for (int i = 0; i < tlen; ++i) {
-		const uint32_t W = u8_score_word(sq.t(ix, i));
+		const uint32_t W = u8_score_word(sq.t(i));
 		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
 #pragma unroll
 		for (int j = 0; j < SL; ++j) {
@@ -165,14 +165,19 @@ __device__ U8Res sw_u8_pass_g16(const IndexView &ix, const SwSeqs &sq, int qlen,
 
 // one rescue alignment per 16-lane group: forward pass, then the pass over the reversed prefixes (ksw.c:343-365)
 template <int SL>
-__device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_ms, int64_t rb, int tlen, uint8_t *rowmax, U8Res *out)
+__device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_ms, int64_t rb, int tlen, uint8_t *rowmax, uint8_t *tl, U8Res *out)
 {
 	const int xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
-	SwSeqs sq{mate, l_ms, rb, 0, 0};
-	U8Res r = sw_u8_pass_g16<SL>(ix, sq, l_ms, tlen, xtra, rowmax);
+	// a per-row load of the reference base would put HBM latency on the critical path of every row: fetch the window once
+	for (int k = __lane_id() & 15; k < tlen; k += 16) tl[k] = (uint8_t)ref_base(ix, rb + k);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	SwSeqs sq{mate, l_ms, tl, 0, 0};
+	U8Res r = sw_u8_pass_g16<SL>(sq, l_ms, tlen, xtra, rowmax);
 	if (!(r.score < (xtra & 0xffff))) {
-		SwSeqs s2{mate, l_ms, rb, r.qe + 1, r.te + 1};
-		U8Res rr = sw_u8_pass_g16<SL>(ix, s2, r.qe + 1, tlen, KSW_XSTOP | r.score, rowmax);
+		SwSeqs s2{mate, l_ms, tl, r.qe + 1, r.te + 1};
+		U8Res rr = sw_u8_pass_g16<SL>(s2, r.qe + 1, tlen, KSW_XSTOP | r.score, rowmax);
 		if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
 	}
 	if ((__lane_id() & 15) == 0) *out = r;
@@ -185,11 +190,13 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
                                                   const SwTask *tasks, U8Res *res, int n)
 {
 	__shared__ uint8_t rowmax_lds[4][SW_T_CAP];
+	__shared__ uint8_t target_lds[4][SW_T_CAP];
 	const int g = threadIdx.x >> 4;
 	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
 		const SwTask t = tasks[i];
 		const int r = 2 * t.pair + t.o;
-		sw_u8_align_g16<SL>(ix, bases + base_off[r], lens[r], t.rb, (int)(t.re - t.rb), rowmax_lds[g], &res[t.slot]);
+		sw_u8_align_g16<SL>(ix, bases + base_off[r], lens[r], t.rb, (int)(t.re - t.rb), rowmax_lds[g], target_lds[g], &res[t.slot]);
+		__builtin_amdgcn_wave_barrier(); // the LDS rows are reused by the group's next alignment
 	}
 }
 
@@ -203,8 +210,9 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
 // (largest column wins) and the adaptive band, the latter two as group reductions.  Columns outside [beg, end] keep
 // their stale values exactly as the reference's array does, which is what makes the shrinking/growing band bit-exact.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int EXT_T_CAP = 512;
 template <int C>
-__device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtTask &t)
+__device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtTask &t, uint8_t *tl)
 {
 	const int l = __lane_id() & 15;
 	const int qlen = t.qlen, tlen = t.tlen, h0 = t.h0;
@@ -226,9 +234,16 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 		mg = mg > 1 ? mg : 1;
 		w = w < mg ? w : mg;
 	}
+	// the target once into LDS (a per-row load would put HBM latency on every row's critical path); rows beyond the staging
+	// capacity, which only very long reads reach, load directly
+	const int n_stage = tlen < EXT_T_CAP ? tlen : EXT_T_CAP;
+	for (int k = l; k < n_stage; k += 16) tl[k] = (uint8_t)ref_base(ix, t.tpos + (int64_t)k * t.tdir);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = ref_base(ix, t.tpos + (int64_t)i * t.tdir);
+		const int tb = i < EXT_T_CAP ? tl[i] : ref_base(ix, t.tpos + (int64_t)i * t.tdir);
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -334,11 +349,13 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 template <int C>
 __global__ void __launch_bounds__(64) k_extend_g16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
 {
+	__shared__ uint8_t target_lds[4][EXT_T_CAP];
 	const int g = threadIdx.x >> 4;
 	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
 		const ExtTask t = tasks[i];
-		ExtRes r = ext2_g16<C>(ix, bases, t);
+		ExtRes r = ext2_g16<C>(ix, bases, t, target_lds[g]);
 		if ((threadIdx.x & 15) == 0) res[t.owner] = r;
+		__builtin_amdgcn_wave_barrier(); // the LDS row is reused by the group's next extension
 	}
 }
 

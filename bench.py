@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
     ap.add_argument("--lib", default=None, help="(dry runs of this script only) alternative library exporting the C ABI")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for the CPU dry run of the sharding logic)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,12 +142,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
         def barrier():
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
     else:
         def barrier():
             pass
@@ -207,14 +212,20 @@ def main():
     dt = time.time() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ktimes = ref.kernel_times()
     counts = [b.counts() for b in batches]
+    # what every rank did (control plane only; the data path has no collective): pairs and regions per step
+    mine = dict(rank=rank, pairs=int(rs.n_pairs), regs=int(sum(c["n_regs"] for c in counts)), read_seed=SEED0 + 1000 * rank)
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
-        pairs_per_step = rs.n_pairs * world
+        pairs_per_step = sum(r["pairs"] for r in per_rank)
         value = pairs_per_step * args.steps / dt
         out = dict(metric="paired reads/sec through the per-barcode alignment path (seed+extend+rescue+CIGAR%s), GRCh38 chr20-size, 2x150bp" % ("" if args.no_rfa else "+RFA placement+MAPQ"),
                    value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -223,6 +234,7 @@ def main():
                    config=dict(workload="BASELINE.json configs[1]: GRCh38 chr20-size genome (%d bp synthetic, planted repeats), "
                                         "%d barcodes x %d pairs 2x150bp per GPU" % (args.genome_len, args.barcodes, args.pairs_per_barcode),
                                pairs_per_step_per_gpu=rs.n_pairs, device_batches=len(batches), parallelism=f"barcode-sharded x{world}"))
+        out["per_rank"] = per_rank
         # roofline of the seeding kernel (the HBM-bound headline)
         try:
             ab = algorithmic_bytes(prefix, rs, 10_000)
