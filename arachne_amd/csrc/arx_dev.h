@@ -36,6 +36,10 @@ constexpr int KSW_XBYTE = 0x10000, KSW_XSTOP = 0x20000, KSW_XSUBO = 0x40000, KSW
 constexpr int PES_LOW = -35, PES_HIGH = 500, MAX_RESCUE = 50;
 
 constexpr int MAX_READ_LEN = 249;   // u8 rescue SW is only exact below 250 (bwamem_pair.c:150)
+// Extensions are binned by query length so that a wavefront's four 16-lane groups run the same register tiling
+// (hip_sw_coop.h: C columns per lane, 16 * C > qlen)
+constexpr int EXT_CLASSES = 4;
+ARX_DEVI int ext_class(int qlen) { return qlen < 64 ? 0 : qlen < 112 ? 1 : qlen < 160 ? 2 : 3; }
 constexpr int CAP_INTV = 256;       // SMEM intervals kept per read (overflow is reported, never truncated silently)
 
 // error bits raised by kernels into Pipeline::d_err

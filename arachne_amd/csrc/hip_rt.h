@@ -211,16 +211,23 @@ struct HipRT {
 		hipLaunchKernelGGL(k_locate_dyn, dim3(blocks), dim3(256), 0, stream, f.ix, f.occ_seed, n, counter);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
-	// banded extension: 16 lanes per extension (hip_sw_coop.h)
-	template <class F> void run_extend(const char *nm, int n, const F &f, int max_len)
+	// banded extension: 16 lanes per extension (hip_sw_coop.h), one launch per query-length class
+	template <class F> void run_extend(const char *nm, const int32_t *n_class, int stride, const F &f)
 	{
-		if (n <= 0) return;
-		if (sw_simple) { launch_rows(nm, n, f, max_len + 1); return; }
-		Scope sc(*this, nm, n);
-		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
-		if (max_len <= 159) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, f.res, n);
-		else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, f.res, n);
-		ARX_HIP_CHECK(hipGetLastError());
+		static const char *names[EXT_CLASSES] = { "extend_q64", "extend_q112", "extend_q160", "extend_q256" };
+		for (int c = 0; c < EXT_CLASSES; ++c) {
+			const int n = n_class[c];
+			if (n <= 0) continue;
+			F fc = f; fc.tasks = f.tasks + (size_t)c * stride;
+			if (sw_simple) { launch_rows(nm, n, fc, MAX_READ_LEN + 2); continue; }
+			Scope sc(*this, names[c], n);
+			int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
+			if (c == 0) hipLaunchKernelGGL(k_extend_g16<4>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
+			else if (c == 1) hipLaunchKernelGGL(k_extend_g16<7>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
+			else if (c == 2) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
+			else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
+			ARX_HIP_CHECK(hipGetLastError());
+		}
 	}
 	// CIGARs of the gapped regions: 16 lanes per region (hip_nw_coop.h); f is pipeline.h's KReg2Aln
 	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *zbuf, const int32_t *z_off)

@@ -202,13 +202,15 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
 
 // ------------------------------------------------------------------------------------------------------------------
 // ext2_g16: banded extension (ksw_extend2, ksw.c:380-479) by a 16-lane group, four extensions per wavefront.
-// Column j of the reference's eh[] array lives in lane j / Cw, register j % Cw.  Within a row, M(i,j) only depends on the
-// previous row, and both gap states are fed from M (not H), so the row is evaluated in three sweeps instead of a serial
-// chain: (1) M and the insertion seeds t(j) = max(M(j) - 7, 0); (2) F(j) = max_{beg<=k<j} (t(k) + k) - (j - 1), a prefix
-// maximum done per lane and then across the 16 lanes with a 4-step scan (the max-plus form of the serial
-// f = max(f - 1, t) chain, exact because every t is >= 0); (3) H, E, the row maximum with the reference's tie rule
-// (largest column wins) and the adaptive band, the latter two as group reductions.  Columns outside [beg, end] keep
-// their stale values exactly as the reference's array does, which is what makes the shrinking/growing band bit-exact.
+// Column j of the reference's eh[] array lives in lane j / C, register j % C (C columns per lane, 16*C > qlen: the kernel is
+// instantiated for a few C and extensions are binned by query length).  Within a row, M(i,j) only depends on the previous
+// row, and both gap states are fed from M (not H), so the row is evaluated in sweeps instead of a serial chain: (1) M and the
+// insertion seeds t(j) = max(M(j) - 7, 0); (2) F(j) = max_{beg<=k<j} (t(k) + k) - (j - 1), a prefix maximum done per lane
+// and then across the 16 lanes with a 4-step scan (the max-plus form of the serial f = max(f - 1, t) chain, exact because
+// every t is >= 0); (3) H, E, the row maximum with the reference's tie rule (largest column wins) and the adaptive band,
+// the latter as group reductions.  Columns outside [beg, end] keep their stale values exactly as the reference's array
+// does, which is what makes the shrinking/growing band bit-exact.  The row body is straight-line select code: every lane
+// runs the same instructions, so predication costs nothing and branches would.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int EXT_T_CAP = 512;
 template <int C>
@@ -216,17 +218,17 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 {
 	const int l = __lane_id() & 15;
 	const int qlen = t.qlen, tlen = t.tlen, h0 = t.h0;
-	const int Cw = (qlen + 16) >> 4; // ceil((qlen + 1) / 16) columns per lane
-	const int c0 = l * Cw;
-	const int NEG = -0x40000000;
-	int H[C], E[C], Q[C], Mv[C], hv[C], pref[C];
+	const int c0 = l * C;
+	const int NEG = -0x40000000, BIG = 0x7fff;
+	int H[C], E[C], Q[C], MIS[C], Mv[C], hv[C], pref[C];
 #pragma unroll
 	for (int u = 0; u < C; ++u) {
 		const int j = c0 + u;
 		int v = j == 0 ? h0 : h0 - 6 - j; // first row (ksw.c:395-397): h0, h0-7, then minus one per column while positive
 		H[u] = v > 0 ? v : 0;
 		E[u] = 0;
-		Q[u] = (u < Cw && j < qlen) ? bases[t.qoff + j * t.qdir] : 4;
+		Q[u] = j < qlen ? bases[t.qoff + j * t.qdir] : 4;
+		MIS[u] = Q[u] > 3 ? -1 : -OPT_B; // the target never holds an N (2-bit pac)
 	}
 	int w = t.w;
 	{
@@ -249,17 +251,20 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 		if (end > qlen) end = qlen;
 		int h1init = 0;
 		if (beg == 0) { h1init = h0 - (OPT_O_DEL + OPT_E_DEL * (i + 1)); if (h1init < 0) h1init = 0; }
+		const unsigned nb = end > beg ? (unsigned)(end - beg) : 0u; // beg can pass end once the rows run beyond the query: empty row, m == 0 ends it
+		const int jb0 = c0 - beg; // column - beg for register 0
 		// sweep 1: M, and the running maximum of t(k) + k inside the lane
 		int pm = NEG;
 #pragma unroll
 		for (int u = 0; u < C; ++u) {
-			const int j = c0 + u;
-			const bool act = u < Cw && j >= beg && j < end;
-			int M = act && H[u] ? H[u] + sc_mat(tb, Q[u]) : 0;
+			const bool act = (unsigned)(jb0 + u) < nb;
+			const int sc = Q[u] == tb ? OPT_A : MIS[u];
+			const int M = (act && H[u] != 0) ? H[u] + sc : 0;
 			Mv[u] = M;
 			int tv = M - 7; tv = tv > 0 ? tv : 0;
 			pref[u] = pm;
-			if (act) { int key = tv + j; pm = pm > key ? pm : key; }
+			const int key = act ? tv + (c0 + u) : NEG;
+			pm = pm > key ? pm : key;
 		}
 		// exclusive prefix maximum of the lane maxima across the group
 		int x = pm, y;
@@ -268,45 +273,48 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 		y = g16_shift_up_n<4>(x, NEG); x = x > y ? x : y;
 		y = g16_shift_up_n<8>(x, NEG); x = x > y ? x : y;
 		const int ex = g16_shift_up_n<1>(x, NEG);
-		// sweep 2: F, H, E and the lane's row maximum (largest column wins ties, ksw.c:437)
-		int m_loc = -1, mj_loc = -1;
+		// sweep 2: F, H, E and the lane's row maximum as (h << 8 | column): the largest column wins ties (ksw.c:437)
+		int best = -1;
 #pragma unroll
 		for (int u = 0; u < C; ++u) {
 			const int j = c0 + u;
-			const bool act = u < Cw && j >= beg && j < end;
-			if (act) {
-				int pmx = ex > pref[u] ? ex : pref[u];
-				int F = j == beg ? 0 : pmx - (j - 1);
-				int h = Mv[u] > E[u] ? Mv[u] : E[u];
-				h = h > F ? h : F;
-				hv[u] = h;
-				int e = E[u] - 1, tt = Mv[u] - 7;
-				e = e > tt ? e : tt;
-				E[u] = e > 0 ? e : 0;
-				if (h >= m_loc) { m_loc = h; mj_loc = j; }
-			} else hv[u] = 0;
+			const bool act = (unsigned)(jb0 + u) < nb;
+			const int pmx = ex > pref[u] ? ex : pref[u];
+			const int F = pmx - (j - 1); // at j == beg this is hugely negative, like the serial chain's f = 0 it never beats M, E >= 0
+			int h = Mv[u] > E[u] ? Mv[u] : E[u];
+			h = h > F ? h : F;
+			hv[u] = act ? h : 0;
+			int tv = Mv[u] - 7; tv = tv > 0 ? tv : 0;
+			int e = E[u] - 1; e = e > tv ? e : tv;
+			E[u] = act ? e : E[u];
+			const int pk = act ? (h << 8 | j) : -1;
+			best = best > pk ? best : pk;
 		}
-		// sweep 3: eh[j].h <- H(i, j-1): shift by one column, across the lane boundary by one lane
-		int last_h = 0;
+		// sweep 3: eh[j].h <- H(i, j-1): shift by one column, across the lane boundary by one lane; eh[beg].h <- h1, eh[end].e <- 0;
+		// then the adaptive band (ksw.c:466-469) on the freshly written row: first / last column of [beg, end] that is not all zero
+		const int from_prev = g16_shift_up_n<1>(hv[C - 1], 0);
+		int first = BIG, last = -1;
 #pragma unroll
-		for (int u = 0; u < C; ++u) if (u == Cw - 1) last_h = hv[u];
-		const int from_prev = g16_shift_up_n<1>(last_h, 0);
-#pragma unroll
-		for (int u = C - 1; u >= 0; --u) {
+		for (int u = 0; u < C; ++u) {
 			const int j = c0 + u;
-			if (u < Cw && j <= qlen) {
-				if (j > beg && j <= end) H[u] = u == 0 ? from_prev : hv[u - 1];
-				else if (j == beg) H[u] = h1init;
-				if (j == end) { E[u] = 0; if (j == beg) H[u] = h1init; }
-			}
+			const int prev = u == 0 ? from_prev : hv[u > 0 ? u - 1 : 0];
+			const bool shifted = (unsigned)(jb0 + u - 1) < nb; // beg < j <= end
+			int hn = shifted ? prev : H[u];
+			hn = j == beg ? h1init : hn;
+			H[u] = hn;
+			const int en = j == end ? 0 : E[u];
+			E[u] = en;
+			const bool nz = (hn | en) != 0;
+			const bool in_row = (unsigned)(jb0 + u) <= nb; // beg <= j <= end
+			first = (nz && in_row && j != end && j < first) ? j : first;
+			last = (nz && in_row) ? j : last; // u ascends: the last hit is the largest column of this lane
 		}
-		// row maximum and its column; the value entering column `end`
-		int packed = g16_max(m_loc < 0 ? -1 : (m_loc << 12) | mj_loc); // mj_loc < 4096
-		int m = packed < 0 ? 0 : packed >> 12, mj = packed < 0 ? -1 : packed & 0xfff;
+		const int packed = g16_max(best);
+		const int m = packed < 0 ? 0 : packed >> 8, mj = packed < 0 ? -1 : packed & 0xff;
 		if (end == qlen) {
 			int own = -1;
 #pragma unroll
-			for (int u = 0; u < C; ++u) if (u < Cw && c0 + u == end - 1 && end - 1 >= beg) own = hv[u];
+			for (int u = 0; u < C; ++u) own = (c0 + u == end - 1 && end - 1 >= beg) ? hv[u] : own;
 			int h1 = g16_max(own);
 			if (h1 < 0) h1 = h1init; // empty row: h1 keeps its initial value
 			max_ie = gscore > h1 ? max_ie : i;
@@ -321,22 +329,9 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 			if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * OPT_E_DEL > OPT_ZDROP) break; }
 			else { if (max - m - ((mj - max_j) - (i - max_i)) * OPT_E_INS > OPT_ZDROP) break; }
 		}
-		// adaptive band (ksw.c:466-469) on the freshly written row
-		int first = 0x7fffffff;
-#pragma unroll
-		for (int u = C - 1; u >= 0; --u) {
-			const int j = c0 + u;
-			if (u < Cw && j >= beg && j < end && (H[u] != 0 || E[u] != 0)) first = j;
-		}
 		first = g16_min(first);
-		const int nbeg = first < end ? first : end;
-		int last = -1;
-#pragma unroll
-		for (int u = 0; u < C; ++u) {
-			const int j = c0 + u;
-			if (u < Cw && j >= nbeg && j <= end && j <= qlen && (H[u] != 0 || E[u] != 0)) last = j;
-		}
 		last = g16_max(last);
+		const int nbeg = first < end ? first : end;
 		if (last < nbeg) last = nbeg - 1;
 		beg = nbeg;
 		end = last + 2 < qlen ? last + 2 : qlen;

@@ -84,8 +84,11 @@ struct KChain {
 struct KExtStep {
 	IndexView ix; const int32_t *base_off, *lens, *occ_off, *n_chain; const Chain *chains; const Seed *seeds; int32_t *srt; Reg *regs;
 	ExtState *state; const ExtRes *res; ExtTask *tasks; int32_t *n_tasks; int first;
-	ARX_DEV void operator()(int r, int) const
+	int task_stride;                              // tasks + c * task_stride: the list of length class c, n_tasks[c] its length
+	const int32_t *act_in; int32_t *act_out;      // reads still extending (null in the first round: all); n_tasks[EXT_CLASSES] counts act_out
+	ARX_DEV void operator()(int item, int) const
 	{
+		const int r = act_in ? act_in[item] : item;
 		ExtState st;
 		if (first) { st = ExtState(); st.ci = -1; st.k = -1; st.phase = PH_PICK; st.n_regs = 0; }
 		else { st = state[r]; if (st.phase == PH_DONE) return; }
@@ -94,7 +97,11 @@ struct KExtStep {
 		ExtRes rs = first ? ExtRes() : res[r];
 		bool more = ext_step(ix, r, base_off[r], lens[r], chains + g0, n_chain[r], seeds, srt, regs + g0, st, rs, t);
 		state[r] = st;
-		if (more) tasks[claim(n_tasks)] = t;
+		if (more) {
+			const int c = ext_class(t.qlen);
+			tasks[(size_t)c * task_stride + claim(n_tasks + c)] = t;
+			act_out[claim(n_tasks + EXT_CLASSES)] = r;
+		}
 	}
 	static ARX_DEVI int claim(int32_t *ctr) { return ARX_ATOMIC_INC(ctr); }
 };
@@ -322,21 +329,28 @@ public:
 	{
 		const int R = b.n_reads; const size_t T = (size_t)w.T + 1; const int slots = rt.max_slots();
 		w.srt = rt.template alloc<int32_t>(T); w.regs = rt.template alloc<Reg>(T); w.rtmp = rt.template alloc<Reg>(T); w.idx = rt.template alloc<int32_t>(T);
-		w.est = rt.template alloc<ExtState>(R + 1); w.etask = rt.template alloc<ExtTask>(R + 1); w.eres = rt.template alloc<ExtRes>(R + 1);
+		w.est = rt.template alloc<ExtState>(R + 1); w.etask = rt.template alloc<ExtTask>((size_t)EXT_CLASSES * (R + 1)); w.eres = rt.template alloc<ExtRes>(R + 1);
+		int32_t *act[2] = { rt.template alloc<int32_t>(R + 1), rt.template alloc<int32_t>(R + 1) };
+		int32_t *ecnt = rt.template alloc<int32_t>(EXT_CLASSES + 1);
+		int n_act = R;
 		w.n_core = rt.template alloc<int32_t>(R + 1);
 		const int eh_words = 2 * (b.max_len + 2);
 		w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
 		for (int round = 0;; ++round) {
-			rt.memset0(w.counter, 4);
-			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, w.n_chain, w.cout, w.sout, w.srt, w.regs, w.est, w.eres, w.etask, w.counter, round == 0};
-			rt.launch("ext_step", R, ks);
-			int nt = read_counter(w);
+			rt.memset0(ecnt, 4 * (EXT_CLASSES + 1));
+			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, w.n_chain, w.cout, w.sout, w.srt, w.regs, w.est, w.eres, w.etask, ecnt, round == 0,
+			            R + 1, round == 0 ? nullptr : act[round & 1], act[(round + 1) & 1]};
+			rt.launch("ext_step", n_act, ks);
+			int32_t cnt[EXT_CLASSES + 1];
+			rt.d2h(cnt, ecnt, 4 * (EXT_CLASSES + 1));
+			int nt = cnt[EXT_CLASSES];
+			n_act = nt; // a read that queued an extension is the only kind that comes back
 			if (trace) { fprintf(stderr, "[arx] ext round %d: %d tasks\n", round, nt); fflush(stderr); }
 			if (nt == 0) break;
 			if (round > w.T + R + 8) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; } // cannot happen: every round retires a DP
 			out.n_ext_tasks += nt; ++out.ext_rounds;
 			KExtend ke{ix, b.bases, w.etask, w.eres};
-			rt.run_extend("extend", nt, ke, b.max_len);
+			rt.run_extend("extend", cnt, R + 1, ke);
 			if (trace) { rt.sync(); fprintf(stderr, "[arx]   extend kernel done\n"); fflush(stderr); }
 		}
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }

@@ -87,7 +87,10 @@ struct SimRT {
 	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
 	template <class F> void run_locate(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
-	template <class F> void run_extend(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, max_len + 1); }
+	template <class F> void run_extend(const char *nm, const int32_t *n_class, int stride, const F &f)
+	{
+		for (int c = 0; c < EXT_CLASSES; ++c) { F fc = f; fc.tasks = f.tasks + (size_t)c * stride; launch_rows(nm, n_class[c], fc, MAX_READ_LEN + 2); }
+	}
 	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *, const int32_t *) { launch(nm, n, f); }
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words)
 	{
