@@ -69,6 +69,25 @@ ARX_DEVI void occ4(const IndexView &ix, uint64_t k, uint64_t cnt[4])
 	cnt[0] = b.cum[0] + c4[0]; cnt[1] = b.cum[1] + c4[1]; cnt[2] = b.cum[2] + c4[2]; cnt[3] = b.cum[3] + c4[3];
 }
 
+// bwt_2occ4 (bwt.c:189-217): both ends of an interval; when they fall into the same 64-byte block it is fetched once
+ARX_DEVI void occ4_pair(const IndexView &ix, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
+{
+	if (k == (uint64_t)-1 || l == (uint64_t)-1) { occ4(ix, k, ck); occ4(ix, l, cl); return; }
+	k -= (k >= ix.primary); l -= (l >= ix.primary);
+	const OccBlock b = load_block(ix.bwt + ((k >> 7) << 4));
+	uint32_t c4[4];
+	block_count4(b, (int)(k & 127) + 1, c4);
+	ck[0] = b.cum[0] + c4[0]; ck[1] = b.cum[1] + c4[1]; ck[2] = b.cum[2] + c4[2]; ck[3] = b.cum[3] + c4[3];
+	if ((l >> 7) == (k >> 7)) {
+		block_count4(b, (int)(l & 127) + 1, c4);
+		cl[0] = b.cum[0] + c4[0]; cl[1] = b.cum[1] + c4[1]; cl[2] = b.cum[2] + c4[2]; cl[3] = b.cum[3] + c4[3];
+	} else {
+		const OccBlock b2 = load_block(ix.bwt + ((l >> 7) << 4));
+		block_count4(b2, (int)(l & 127) + 1, c4);
+		cl[0] = b2.cum[0] + c4[0]; cl[1] = b2.cum[1] + c4[1]; cl[2] = b2.cum[2] + c4[2]; cl[3] = b2.cum[3] + c4[3];
+	}
+}
+
 // bwt_occ (bwt.c:107-130) for one symbol
 ARX_DEVI uint64_t occ1(const IndexView &ix, uint64_t k, int c)
 {
@@ -85,8 +104,7 @@ ARX_DEVI Biv extend1(const IndexView &ix, const Biv &ik, int is_back, int c)
 {
 	uint64_t a = is_back ? ik.k : ik.l, b = is_back ? ik.l : ik.k;
 	uint64_t tk[4], tl[4];
-	occ4(ix, a - 1, tk);
-	occ4(ix, a - 1 + ik.s, tl);
+	occ4_pair(ix, a - 1, a - 1 + ik.s, tk, tl);
 	uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1];
 	uint64_t x = b + (a <= ix.primary && a + ik.s - 1 >= ix.primary); // position of child 3 on the other strand
 	if (c < 3) x += s3;
@@ -133,104 +151,118 @@ struct SmemScratch { Biv *v0, *v1, *mem; };
 // mem_collect_intv (bwamem.c:114-162): SMEM pass (bwt_smem1a, bwt.c:289-351, max_intv = 0), re-seeding pass from the
 // middle of long rare SMEMs, LAST-like pass (bwt_seed_strategy1, bwt.c:358-379), then sort by info.
 //
-// The reference nests these loops around bwt_extend(); here they are flattened into one state machine that performs at
-// most ONE extend1() per iteration at a single place in the code, so that the 64 reads of a wavefront -- each somewhere
-// else in its own forward/backward search -- reconverge on the only expensive step (two random 64-byte Occ blocks).
-// Entries with equal info describe the same query substring and hence the same bi-interval, so any sort reproduces
-// ks_introsort's result.  Returns the number of intervals written to out (capacity cap); *overflow is set when more were found.
-ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const SmemScratch &sc, Biv *out, int cap, int *overflow)
-{
+// The reference nests these loops around bwt_extend(); here they are flattened into a resumable lane program: advance()
+// runs the bookkeeping of one read until it needs its next extension (the only expensive step: two random 64-byte Occ
+// blocks) or is finished, consume() takes the extension's result.  A caller that drives many lanes (hip_fm_coop.h) lets
+// the 64 reads of a wavefront -- each somewhere else in its own forward/backward search -- reconverge on extend1(), and
+// gives a lane its next read as soon as the previous one is finished.  Entries with equal info describe the same query
+// substring and hence the same bi-interval, so any sort reproduces ks_introsort's result.
+struct QBytes { const uint8_t *p; ARX_DEVI int at(int i) const { return p[i]; } };       // base codes 0..4, one per byte
+struct QNibbles { const uint8_t *p; ARX_DEVI int at(int i) const { return (p[i >> 1] >> ((i & 1) << 2)) & 15; } }; // two per byte (LDS staging)
+
+template <class Q> struct SeedLane {
 	enum { ST_P1_NEXT, ST_P2_NEXT, ST_P3_NEXT, ST_FWD, ST_FWD_DONE, ST_BWD_ROW, ST_BWD_J, ST_SMEM_DONE, ST_STRAT, ST_DONE };
-	Biv *prev = sc.v0, *curr = sc.v1, *mem = sc.mem;
-	int state = ST_P1_NEXT, pass = 1;
-	int n = 0, old_n = 0, k2 = 0;            // output count; pass-2 bookkeeping
-	int x = 0, min_intv = 1, ret = 0;        // current smem1 call
-	int i = 0, j = 0, c = 0, n_prev = 0, n_curr = 0, nm = 0, sx = 0;
-	Biv ik = Biv();
-	while (state != ST_DONE) {
-		Biv req = Biv();
-		int rb = 0, rc = 0;
-		bool need = false;
-		// bookkeeping runs per lane until this read needs its next extension (or is finished); the lanes of a wave then
-		// reconverge on extend1() below instead of alternating between bookkeeping and extension iterations
-		do {
-		switch (state) {
-		case ST_P1_NEXT:
-			while (x < len && q[x] > 3) ++x;
-			if (x >= len) { old_n = n; k2 = 0; pass = 2; state = ST_P2_NEXT; break; }
-			min_intv = 1; ik = set_intv(ix, q[x]); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
-			break;
-		case ST_P2_NEXT: {
-			bool found = false;
-			while (k2 < old_n) { // re-seed from the middle of SMEMs that are long and occur rarely
-				const Biv p = out[k2];
-				const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
-				if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) { ++k2; continue; }
-				x = (start + end) >> 1; min_intv = (int)p.s + 1;
-				found = true;
+	Biv *prev, *curr, *mem, *out;
+	Q q;
+	int len, cap, overflow;
+	int state, pass;
+	int n, old_n, k2;               // output count; pass-2 bookkeeping
+	int x, min_intv, ret;           // current smem1 call
+	int i, j, c, n_prev, n_curr, nm, sx;
+	Biv ik;
+
+	ARX_DEVI void start(const SmemScratch &sc, int len_, const Q &q_, Biv *out_, int cap_)
+	{
+		prev = sc.v0; curr = sc.v1; mem = sc.mem; out = out_; q = q_; len = len_; cap = cap_; overflow = 0;
+		state = ST_P1_NEXT; pass = 1; n = old_n = k2 = 0; x = 0; min_intv = 1; ret = 0;
+		i = j = c = n_prev = n_curr = nm = sx = 0; ik = Biv();
+	}
+	ARX_DEVI bool done() const { return state == ST_DONE; }
+
+	// bookkeeping until the read needs an extension (true: *req extended by symbol *rc, backward if *rb) or is finished (false)
+	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rb, int *rc)
+	{
+		while (state != ST_DONE) {
+			switch (state) {
+			case ST_P1_NEXT:
+				while (x < len && q.at(x) > 3) ++x;
+				if (x >= len) { old_n = n; k2 = 0; pass = 2; state = ST_P2_NEXT; break; }
+				min_intv = 1; ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
+				break;
+			case ST_P2_NEXT: {
+				bool found = false;
+				while (k2 < old_n) { // re-seed from the middle of SMEMs that are long and occur rarely
+					const Biv p = out[k2];
+					const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
+					if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) { ++k2; continue; }
+					x = (start + end) >> 1; min_intv = (int)p.s + 1;
+					found = true;
+					break;
+				}
+				if (!found) { x = 0; state = ST_P3_NEXT; break; }
+				if (q.at(x) > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
+				ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
 				break;
 			}
-			if (!found) { x = 0; state = ST_P3_NEXT; break; }
-			if (q[x] > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
-			ik = set_intv(ix, q[x]); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
-			break;
-		}
-		case ST_P3_NEXT:
-			while (x < len && q[x] > 3) ++x;
-			if (x >= len) { state = ST_DONE; break; }
-			ik = set_intv(ix, q[x]); sx = x; i = x + 1; state = ST_STRAT;
-			break;
-		case ST_FWD: // forward extension at query position i; the interval is remembered each time its size changes
-			if (i >= len || q[i] > 3) { curr[n_curr++] = ik; state = ST_FWD_DONE; break; }
-			req = ik; rb = 0; rc = 3 - q[i]; need = true;
-			break;
-		case ST_FWD_DONE: {
-			for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
-			ret = (int)curr[0].info;
-			Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-			i = x - 1; state = ST_BWD_ROW;
-			break;
-		}
-		case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
-			if (i < -1) { state = ST_SMEM_DONE; break; }
-			c = i < 0 ? -1 : (q[i] < 4 ? q[i] : -1);
-			n_curr = 0; j = 0;
-			if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
-				if (n_prev > 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
-				state = ST_SMEM_DONE;
+			case ST_P3_NEXT:
+				while (x < len && q.at(x) > 3) ++x;
+				if (x >= len) { finish(); break; }
+				ik = set_intv(ix, q.at(x)); sx = x; i = x + 1; state = ST_STRAT;
 				break;
-			}
-			state = ST_BWD_J;
-			break;
-		case ST_BWD_J:
-			if (j >= n_prev) {
-				if (n_curr == 0) { state = ST_SMEM_DONE; break; }
+			case ST_FWD: // forward extension at query position i; the interval is remembered each time its size changes
+				if (i >= len || q.at(i) > 3) { curr[n_curr++] = ik; state = ST_FWD_DONE; break; }
+				*req = ik; *rb = 0; *rc = 3 - q.at(i);
+				return true;
+			case ST_FWD_DONE: {
+				for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
+				ret = (int)curr[0].info;
 				Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-				--i; state = ST_BWD_ROW;
+				i = x - 1; state = ST_BWD_ROW;
 				break;
 			}
-			req = prev[j]; rb = 1; rc = c; need = true;
-			break;
-		case ST_SMEM_DONE:
-			for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
-				const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
-				if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[t]; else *overflow = 1; }
+			case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
+				if (i < -1) { state = ST_SMEM_DONE; break; }
+				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
+				n_curr = 0; j = 0;
+				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
+					if (n_prev > 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
+					state = ST_SMEM_DONE;
+					break;
+				}
+				state = ST_BWD_J;
+				break;
+			case ST_BWD_J:
+				if (j >= n_prev) {
+					if (n_curr == 0) { state = ST_SMEM_DONE; break; }
+					Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+					--i; state = ST_BWD_ROW;
+					break;
+				}
+				*req = prev[j]; *rb = 1; *rc = c;
+				return true;
+			case ST_SMEM_DONE:
+				for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
+					const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
+					if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[t]; else overflow = 1; }
+				}
+				if (pass == 1) { x = ret; state = ST_P1_NEXT; } else { ++k2; state = ST_P2_NEXT; }
+				break;
+			case ST_STRAT: // shortest forward match of > min_seed_len bases occurring < max_mem_intv times
+				if (i >= len) { x = len; state = ST_P3_NEXT; break; }
+				if (q.at(i) > 3) { x = i + 1; state = ST_P3_NEXT; break; }
+				*req = ik; *rb = 0; *rc = 3 - q.at(i);
+				return true;
 			}
-			if (pass == 1) { x = ret; state = ST_P1_NEXT; } else { ++k2; state = ST_P2_NEXT; }
-			break;
-		case ST_STRAT: // shortest forward match of > min_seed_len bases occurring < max_mem_intv times
-			if (i >= len) { x = len; state = ST_P3_NEXT; break; }
-			if (q[i] > 3) { x = i + 1; state = ST_P3_NEXT; break; }
-			req = ik; rb = 0; rc = 3 - q[i]; need = true;
-			break;
 		}
-		} while (!need && state != ST_DONE);
-		if (!need) break;
-		const Biv ok = extend1(ix, req, rb, rc); // the one expensive step
+		return false;
+	}
+	// result of the extension advance() asked for
+	ARX_DEVI void consume(const Biv &req, const Biv &ok)
+	{
 		if (state == ST_FWD) {
 			if (ok.s != ik.s) {
 				curr[n_curr++] = ik;
-				if (ok.s < (uint64_t)min_intv) { state = ST_FWD_DONE; continue; }
+				if (ok.s < (uint64_t)min_intv) { state = ST_FWD_DONE; return; }
 			}
 			ik = ok; ik.info = i + 1; ++i;
 		} else if (state == ST_BWD_J) {
@@ -243,18 +275,40 @@ ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const S
 			++j;
 		} else { // ST_STRAT
 			if (ok.s < (uint64_t)OPT_MAX_MEM_INTV && i - sx >= OPT_MIN_SEED_LEN) {
-				if (ok.s > 0) { Biv t = ok; t.info = (uint64_t)sx << 32 | (uint32_t)(i + 1); if (n < cap) out[n++] = t; else *overflow = 1; }
+				if (ok.s > 0) { Biv t = ok; t.info = (uint64_t)sx << 32 | (uint32_t)(i + 1); if (n < cap) out[n++] = t; else overflow = 1; }
 				x = i + 1; state = ST_P3_NEXT;
 			} else { ik = ok; ++i; }
 		}
 	}
-	for (int a = 1; a < n; ++a) { // insertion sort by info
-		Biv t = out[a];
-		int b = a;
-		while (b > 0 && out[b - 1].info > t.info) { out[b] = out[b - 1]; --b; }
-		out[b] = t;
+	ARX_DEVI void finish() // insertion sort by info
+	{
+		for (int a = 1; a < n; ++a) {
+			Biv t = out[a];
+			int b = a;
+			while (b > 0 && out[b - 1].info > t.info) { out[b] = out[b - 1]; --b; }
+			out[b] = t;
+		}
+		state = ST_DONE;
 	}
-	return n;
+	// seed occurrences the intervals expand to (bwamem.c:273-283: at most max_occ rows per interval)
+	ARX_DEVI int occurrences() const
+	{
+		int occ = 0;
+		for (int a = 0; a < n; ++a) occ += out[a].s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)out[a].s;
+		return occ;
+	}
+};
+
+// one read from start to end.  Returns the number of intervals written to out (capacity cap); *overflow is set when more were found.
+ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const SmemScratch &sc, Biv *out, int cap, int *overflow)
+{
+	SeedLane<QBytes> ln;
+	ln.start(sc, len, QBytes{q}, out, cap);
+	Biv req = Biv();
+	int rb = 0, rc = 0;
+	while (ln.advance(ix, &req, &rb, &rc)) ln.consume(req, extend1(ix, req, rb, rc));
+	if (ln.overflow) *overflow = 1;
+	return ln.n;
 }
 
 } // namespace arx

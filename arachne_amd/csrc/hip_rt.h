@@ -110,7 +110,10 @@ struct HipRT {
 	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }
 
 	// 8 resident 64-thread blocks per CU give every SIMD two waves of these latency-bound kernels
-	int max_blocks() const { return n_cu * 8; }
+	int bpc = getenv("ARX_BPC") ? atoi(getenv("ARX_BPC")) : 8;           // resident 64-lane blocks per CU of the thread-per-item kernels (sizes their per-slot scratch)
+	int coop_bpc = getenv("ARX_COOP_BPC") ? atoi(getenv("ARX_COOP_BPC")) : 8; // grid cap of the 16-lane DP kernels (no per-slot scratch; grid-stride)
+	int max_blocks() const { return n_cu * bpc; }
+	int coop_blocks(int n) const { int b = (n + 3) / 4, cap = n_cu * coop_bpc; return b < cap ? b : cap; }
 	int max_slots() const { return max_blocks() * 64; }
 	int max_slots_small() const { return n_cu * 64; }
 
@@ -195,9 +198,21 @@ struct HipRT {
 		if (n <= 0) return;
 		if (sw_simple) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); return; }
 		Scope sc(*this, nm, n);
-		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
+		int blocks = coop_blocks(n);
 		if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
 		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	// seeding: persistent lanes, reads handed out in chunks (hip_fm_coop.h); f is pipeline.h's KSeed, f.scratch holds max_slots() list triples
+	template <class F> void run_seed(const char *nm, int n, const F &f, int32_t *counter)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch(nm, n, f); return; }
+		memset0(counter, 4);
+		Scope sc(*this, nm, n);
+		SeedArgs A{f.ix, f.bases, f.base_off, f.lens, f.intv, f.n_intv, f.n_occ, f.scratch, f.list_cap, f.err};
+		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
+		hipLaunchKernelGGL(k_seed_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// locate: persistent lanes with wave-level work distribution (hip_fm_coop.h); 32 waves per CU to cover the miss latency
@@ -211,23 +226,28 @@ struct HipRT {
 		hipLaunchKernelGGL(k_locate_dyn, dim3(blocks), dim3(256), 0, stream, f.ix, f.occ_seed, n, counter);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
-	// banded extension: 16 lanes per extension (hip_sw_coop.h), one launch per query-length class
+	// banded extension: 16 lanes per extension (hip_sw_coop.h); the query-length classes share one launch
 	template <class F> void run_extend(const char *nm, const int32_t *n_class, int stride, const F &f)
 	{
-		static const char *names[EXT_CLASSES] = { "extend_q64", "extend_q112", "extend_q160", "extend_q256" };
-		for (int c = 0; c < EXT_CLASSES; ++c) {
-			const int n = n_class[c];
-			if (n <= 0) continue;
-			F fc = f; fc.tasks = f.tasks + (size_t)c * stride;
-			if (sw_simple) { launch_rows(nm, n, fc, MAX_READ_LEN + 2); continue; }
-			Scope sc(*this, names[c], n);
-			int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
-			if (c == 0) hipLaunchKernelGGL(k_extend_g16<4>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
-			else if (c == 1) hipLaunchKernelGGL(k_extend_g16<7>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
-			else if (c == 2) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
-			else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, fc.ix, fc.bases, fc.tasks, fc.res, n);
-			ARX_HIP_CHECK(hipGetLastError());
+		int total = 0;
+		for (int c = 0; c < EXT_CLASSES; ++c) total += n_class[c];
+		if (total <= 0) return;
+		if (sw_simple) {
+			for (int c = 0; c < EXT_CLASSES; ++c) { F fc = f; fc.tasks = f.tasks + (size_t)c * stride; launch_rows(nm, n_class[c], fc, MAX_READ_LEN + 2); }
+			return;
 		}
+		Scope sc(*this, nm, total);
+		ExtClassShape sh;
+		const int cap = n_cu * coop_bpc;
+		int blocks = 0;
+		for (int c = 0; c < EXT_CLASSES; ++c) {
+			sh.n[c] = n_class[c];
+			int nb = (n_class[c] + 3) / 4;
+			if (nb > 0 && (total + 3) / 4 > cap) { nb = (int)((int64_t)nb * cap / ((total + 3) / 4)); if (nb < 1) nb = 1; } // share the grid cap by class size
+			sh.nb[c] = nb; blocks += nb;
+		}
+		hipLaunchKernelGGL(k_extend_classes, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, stride, f.res, sh);
+		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// CIGARs of the gapped regions: 16 lanes per region (hip_nw_coop.h); f is pipeline.h's KReg2Aln
 	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *zbuf, const int32_t *z_off)
@@ -236,7 +256,7 @@ struct HipRT {
 		if (sw_simple) { launch_small(nm, n, f); return; }
 		Scope sc(*this, nm, n);
 		NwArgs A{f.ix, f.bases, f.base_off, f.lens, f.preg_off, f.n_regs, f.n_reads, f.pregs, f.alns, f.cig, f.cig_w, zbuf, z_off, f.nw_list, f.err};
-		int blocks = (n + 3) / 4; if (blocks > max_blocks()) blocks = max_blocks();
+		int blocks = coop_blocks(n);
 		hipLaunchKernelGGL(k_reg2aln_nw_g16, dim3(blocks), dim3(64), 0, stream, A, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}

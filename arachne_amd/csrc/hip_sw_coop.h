@@ -342,16 +342,33 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 }
 
 template <int C>
-__global__ void __launch_bounds__(64) k_extend_g16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
+__device__ __forceinline__ void extend_class_g16(const IndexView &ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n, int blk, int n_blk, uint8_t *tl)
 {
-	__shared__ uint8_t target_lds[4][EXT_T_CAP];
 	const int g = threadIdx.x >> 4;
-	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
+	for (int i = blk * 4 + g; i < n; i += n_blk * 4) {
 		const ExtTask t = tasks[i];
-		ExtRes r = ext2_g16<C>(ix, bases, t, target_lds[g]);
+		ExtRes r = ext2_g16<C>(ix, bases, t, tl);
 		if ((threadIdx.x & 15) == 0) res[t.owner] = r;
 		__builtin_amdgcn_wave_barrier(); // the LDS row is reused by the group's next extension
 	}
+}
+
+// All query-length classes of a round in one launch: blocks [0, nb.x) take class 0, the next nb.y class 1, ...  Every
+// wavefront runs one tiling, and the classes run side by side (late rounds hold few extensions: launched one class after
+// the other, each launch would cost the latency of a whole DP).
+struct ExtClassShape { int n[EXT_CLASSES], nb[EXT_CLASSES]; };
+static __global__ void __launch_bounds__(64) k_extend_classes(IndexView ix, const uint8_t *bases, const ExtTask *tasks, int stride, ExtRes *res, ExtClassShape sh)
+{
+	__shared__ uint8_t target_lds[4][EXT_T_CAP];
+	uint8_t *tl = target_lds[threadIdx.x >> 4];
+	int b = blockIdx.x;
+	if (b < sh.nb[0]) { extend_class_g16<4>(ix, bases, tasks, res, sh.n[0], b, sh.nb[0], tl); return; }
+	b -= sh.nb[0];
+	if (b < sh.nb[1]) { extend_class_g16<7>(ix, bases, tasks + (size_t)stride, res, sh.n[1], b, sh.nb[1], tl); return; }
+	b -= sh.nb[1];
+	if (b < sh.nb[2]) { extend_class_g16<10>(ix, bases, tasks + (size_t)2 * stride, res, sh.n[2], b, sh.nb[2], tl); return; }
+	b -= sh.nb[2];
+	extend_class_g16<16>(ix, bases, tasks + (size_t)3 * stride, res, sh.n[3], b, sh.nb[3], tl);
 }
 
 } // namespace arx

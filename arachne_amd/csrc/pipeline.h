@@ -299,7 +299,7 @@ public:
 		w.smem_scr = rt.template alloc<Biv>((size_t)slots * 3 * list_cap);
 		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
 		KSeed k{ix, b.bases, b.base_off, b.lens, w.intv, w.n_intv, w.n_occ, w.smem_scr, list_cap, w.err};
-		rt.launch("seed", R, k);
+		rt.run_seed("seed", R, k, w.counter);
 		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R);
 		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
 		w.T = total;

@@ -29,7 +29,7 @@ rows = [r for r in (l.rstrip("\n").split("\t") for l in open(log)) if len(r) == 
 by = collections.defaultdict(list)
 for nm, items, ms in rows:
     by[nm].append((int(items), float(ms)))
-for nm in ("extend", "ext_step", "sw_u8", "rescue_step", "reg2aln_nw", "seed"):
+for nm in ("extend", "seed", "ext_step", "sw_u8", "rescue_step", "reg2aln_nw"):
     v = by.get(nm, [])
     print(nm, "launches", len(v), "total ms %.2f" % sum(m for _, m in v))
     for i, (it, ms) in enumerate(v[:12]):
