@@ -179,58 +179,19 @@ template <class Q> struct SeedLane {
 	}
 	ARX_DEVI bool done() const { return state == ST_DONE; }
 
-	// bookkeeping until the read needs an extension (true: *req extended by symbol *rc, backward if *rb) or is finished (false)
-	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rb, int *rc)
+	// Bookkeeping until the read needs an extension (true: *req extended by symbol *rc, backward if *rb) or is finished
+	// (false).  The three states that ask for extensions are cheap; everything between two searches (list reversal, SMEM
+	// output, picking the next start) is rare per lane but long.  With slow_ok = false the lane stops in front of such a
+	// state (false, !done()): a wavefront driver lets lanes queue up there and runs them together, instead of paying for
+	// every rare path in every iteration because one of its 64 lanes is in it.
+	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rb, int *rc, bool slow_ok = true)
 	{
 		while (state != ST_DONE) {
 			switch (state) {
-			case ST_P1_NEXT:
-				while (x < len && q.at(x) > 3) ++x;
-				if (x >= len) { old_n = n; k2 = 0; pass = 2; state = ST_P2_NEXT; break; }
-				min_intv = 1; ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
-				break;
-			case ST_P2_NEXT: {
-				bool found = false;
-				while (k2 < old_n) { // re-seed from the middle of SMEMs that are long and occur rarely
-					const Biv p = out[k2];
-					const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
-					if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) { ++k2; continue; }
-					x = (start + end) >> 1; min_intv = (int)p.s + 1;
-					found = true;
-					break;
-				}
-				if (!found) { x = 0; state = ST_P3_NEXT; break; }
-				if (q.at(x) > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
-				ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
-				break;
-			}
-			case ST_P3_NEXT:
-				while (x < len && q.at(x) > 3) ++x;
-				if (x >= len) { finish(); break; }
-				ik = set_intv(ix, q.at(x)); sx = x; i = x + 1; state = ST_STRAT;
-				break;
 			case ST_FWD: // forward extension at query position i; the interval is remembered each time its size changes
 				if (i >= len || q.at(i) > 3) { curr[n_curr++] = ik; state = ST_FWD_DONE; break; }
 				*req = ik; *rb = 0; *rc = 3 - q.at(i);
 				return true;
-			case ST_FWD_DONE: {
-				for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
-				ret = (int)curr[0].info;
-				Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-				i = x - 1; state = ST_BWD_ROW;
-				break;
-			}
-			case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
-				if (i < -1) { state = ST_SMEM_DONE; break; }
-				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
-				n_curr = 0; j = 0;
-				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
-					if (n_prev > 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
-					state = ST_SMEM_DONE;
-					break;
-				}
-				state = ST_BWD_J;
-				break;
 			case ST_BWD_J:
 				if (j >= n_prev) {
 					if (n_curr == 0) { state = ST_SMEM_DONE; break; }
@@ -240,21 +201,75 @@ template <class Q> struct SeedLane {
 				}
 				*req = prev[j]; *rb = 1; *rc = c;
 				return true;
-			case ST_SMEM_DONE:
-				for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
-					const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
-					if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[t]; else overflow = 1; }
-				}
-				if (pass == 1) { x = ret; state = ST_P1_NEXT; } else { ++k2; state = ST_P2_NEXT; }
-				break;
 			case ST_STRAT: // shortest forward match of > min_seed_len bases occurring < max_mem_intv times
 				if (i >= len) { x = len; state = ST_P3_NEXT; break; }
 				if (q.at(i) > 3) { x = i + 1; state = ST_P3_NEXT; break; }
 				*req = ik; *rb = 0; *rc = 3 - q.at(i);
 				return true;
+			default:
+				if (!slow_ok) return false;
+				slow_step(ix);
+				break;
 			}
 		}
 		return false;
+	}
+	ARX_DEVI bool parked() const { return state != ST_DONE && state != ST_FWD && state != ST_BWD_J && state != ST_STRAT; }
+	ARX_DEV void slow_step(const IndexView &ix)
+	{
+		switch (state) {
+		case ST_P1_NEXT:
+			while (x < len && q.at(x) > 3) ++x;
+			if (x >= len) { old_n = n; k2 = 0; pass = 2; state = ST_P2_NEXT; break; }
+			min_intv = 1; ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
+			break;
+		case ST_P2_NEXT: {
+			bool found = false;
+			while (k2 < old_n) { // re-seed from the middle of SMEMs that are long and occur rarely
+				const Biv p = out[k2];
+				const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
+				if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) { ++k2; continue; }
+				x = (start + end) >> 1; min_intv = (int)p.s + 1;
+				found = true;
+				break;
+			}
+			if (!found) { x = 0; state = ST_P3_NEXT; break; }
+			if (q.at(x) > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
+			ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
+			break;
+		}
+		case ST_P3_NEXT:
+			while (x < len && q.at(x) > 3) ++x;
+			if (x >= len) { finish(); break; }
+			ik = set_intv(ix, q.at(x)); sx = x; i = x + 1; state = ST_STRAT;
+			break;
+		case ST_FWD_DONE: {
+			for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
+			ret = (int)curr[0].info;
+			Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+			i = x - 1; state = ST_BWD_ROW;
+			break;
+		}
+		case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
+			if (i < -1) { state = ST_SMEM_DONE; break; }
+			c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
+			n_curr = 0; j = 0;
+			if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
+				if (n_prev > 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
+				state = ST_SMEM_DONE;
+				break;
+			}
+			state = ST_BWD_J;
+			break;
+		case ST_SMEM_DONE:
+			for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
+				const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
+				if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[t]; else overflow = 1; }
+			}
+			if (pass == 1) { x = ret; state = ST_P1_NEXT; } else { ++k2; state = ST_P2_NEXT; }
+			break;
+		default: break;
+		}
 	}
 	// result of the extension advance() asked for
 	ARX_DEVI void consume(const Biv &req, const Biv &ok)

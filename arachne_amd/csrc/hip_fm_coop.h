@@ -59,7 +59,7 @@ struct SeedArgs {
 	Biv *intv; int32_t *n_intv, *n_occ; Biv *scratch; int list_cap; uint32_t *err;
 };
 
-static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32_t *counter)
+static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32_t *counter, int batch)
 {
 	__shared__ uint8_t q_lds[64 * SEED_ROW];
 	const int lane = threadIdx.x;
@@ -70,60 +70,68 @@ static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32
 	int r = -1;                      // read this lane is searching, -1 = idle
 	int pool_next = 0, pool_end = 0; // wave-uniform: the reserved chunk of reads
 	bool exhausted = false;          // wave-uniform
+	Biv req = Biv();
+	int rb = 0, rc = 0;
+	bool have_req = false;
 	for (;;) {
-		const unsigned long long idle = __ballot(r < 0);
-		if (idle) {
-			if (pool_next == pool_end && !exhausted) {
-				int base = 0;
-				if (lane == 0) base = atomicAdd(counter, SEED_CHUNK);
-				base = __shfl(base, 0);
-				if (base >= n) { exhausted = true; pool_next = pool_end = n; }
-				else { pool_next = base; pool_end = base + SEED_CHUNK < n ? base + SEED_CHUNK : n; }
-			}
-			const int avail = pool_end - pool_next;
-			if (avail > 0) {
-				const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
-				const bool take = r < 0 && rank < avail;
-				if (take) r = pool_next + rank;
-				const int need = __builtin_popcountll(idle);
-				pool_next += need < avail ? need : avail;
-				// the wave copies the bases of every newly taken read into that lane's LDS row, 128 bases per sweep
-				unsigned long long fresh = __ballot(take);
-				while (fresh) {
-					const int src = __builtin_ctzll(fresh);
-					fresh &= fresh - 1;
-					const int rs = __shfl(r, src);
-					const int len = A.lens[rs];
-					const uint8_t *b = A.bases + A.base_off[rs];
-					if (len <= MAX_READ_LEN)
-						for (int k = 2 * lane; k < len; k += 128) {
-							const int lo = b[k], hi = k + 1 < len ? b[k + 1] : 4;
-							q_lds[src * SEED_ROW + (k >> 1)] = (uint8_t)(lo | hi << 4);
-						}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				if (take) {
-					int len = A.lens[r];
-					if (len > MAX_READ_LEN) { atomicOr(A.err, ERR_READ_TOO_LONG); len = 0; }
-					if (len >= OPT_MIN_SEED_LEN) ln.start(sc, len, QNibbles{q_lds + lane * SEED_ROW}, A.intv + (size_t)r * CAP_INTV, CAP_INTV);
-					else { A.n_intv[r] = 0; A.n_occ[r] = 0; r = -1; } // nothing to seed; the lane asks again next time round
-				}
-			} else if (exhausted && idle == ~0ull) break; // nothing left to hand out and nobody is searching (every wave is 64 lanes wide here)
-		}
-		Biv req = Biv();
-		int rb = 0, rc = 0;
-		bool need = false;
-		if (r >= 0) {
-			need = ln.advance(A.ix, &req, &rb, &rc);
-			if (!need) {
+		// cheap part: a lane whose search is in an extending state gets its next request
+		if (r >= 0 && !have_req) have_req = ln.advance(A.ix, &req, &rb, &rc, false);
+		// The rest (finishing a read, taking the next one, the bookkeeping between two searches) is rare per lane but long, and
+		// a wavefront pays for a divergent path whenever ONE lane is in it.  Lanes therefore wait in front of it until `batch`
+		// of them do (or nobody can extend): the wave then runs that code once for all of them.
+		const int waiting = __builtin_popcountll(__ballot(!have_req));
+		if (waiting >= batch || waiting == 64) {
+			// finished reads: write their results
+			if (r >= 0 && !have_req && ln.done()) {
 				A.n_intv[r] = ln.n; A.n_occ[r] = ln.occurrences();
 				if (ln.overflow) atomicOr(A.err, ERR_INTV_OVERFLOW);
 				r = -1;
 			}
+			const unsigned long long idle = __ballot(r < 0);
+			if (idle) {
+				if (pool_next == pool_end && !exhausted) {
+					int base = 0;
+					if (lane == 0) base = atomicAdd(counter, SEED_CHUNK);
+					base = __shfl(base, 0);
+					if (base >= n) { exhausted = true; pool_next = pool_end = n; }
+					else { pool_next = base; pool_end = base + SEED_CHUNK < n ? base + SEED_CHUNK : n; }
+				}
+				const int avail = pool_end - pool_next;
+				if (avail > 0) {
+					const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+					const bool take = r < 0 && rank < avail;
+					if (take) r = pool_next + rank;
+					const int need = __builtin_popcountll(idle);
+					pool_next += need < avail ? need : avail;
+					// the wave copies the bases of every newly taken read into that lane's LDS row, 128 bases per sweep
+					unsigned long long fresh = __ballot(take);
+					while (fresh) {
+						const int src = __builtin_ctzll(fresh);
+						fresh &= fresh - 1;
+						const int rs = __shfl(r, src);
+						const int len = A.lens[rs];
+						const uint8_t *b = A.bases + A.base_off[rs];
+						if (len <= MAX_READ_LEN)
+							for (int k = 2 * lane; k < len; k += 128) {
+								const int lo = b[k], hi = k + 1 < len ? b[k + 1] : 4;
+								q_lds[src * SEED_ROW + (k >> 1)] = (uint8_t)(lo | hi << 4);
+							}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					if (take) {
+						int len = A.lens[r];
+						if (len > MAX_READ_LEN) { atomicOr(A.err, ERR_READ_TOO_LONG); len = 0; }
+						if (len >= OPT_MIN_SEED_LEN) ln.start(sc, len, QNibbles{q_lds + lane * SEED_ROW}, A.intv + (size_t)r * CAP_INTV, CAP_INTV);
+						else { A.n_intv[r] = 0; A.n_occ[r] = 0; r = -1; } // nothing to seed; the lane asks again next time round
+					}
+				} else if (exhausted && idle == ~0ull) break; // nothing left to hand out and nobody is searching (every wave is 64 lanes wide here)
+			}
+			// everything up to the next request (a read that ends here is written out the next time round)
+			if (r >= 0 && !have_req) have_req = ln.advance(A.ix, &req, &rb, &rc, true);
 		}
-		if (need) ln.consume(req, extend1(A.ix, req, rb, rc));
+		if (have_req) { ln.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}
 }
 

@@ -112,6 +112,7 @@ struct HipRT {
 	// 8 resident 64-thread blocks per CU give every SIMD two waves of these latency-bound kernels
 	int bpc = getenv("ARX_BPC") ? atoi(getenv("ARX_BPC")) : 8;           // resident 64-lane blocks per CU of the thread-per-item kernels (sizes their per-slot scratch)
 	int coop_bpc = getenv("ARX_COOP_BPC") ? atoi(getenv("ARX_COOP_BPC")) : 8; // grid cap of the 16-lane DP kernels (no per-slot scratch; grid-stride)
+	int ext_merge_below = getenv("ARX_EXT_MERGE") ? atoi(getenv("ARX_EXT_MERGE")) : 30000; // rounds with fewer extensions run all length classes in one launch
 	int max_blocks() const { return n_cu * bpc; }
 	int coop_blocks(int n) const { int b = (n + 3) / 4, cap = n_cu * coop_bpc; return b < cap ? b : cap; }
 	int max_slots() const { return max_blocks() * 64; }
@@ -212,7 +213,8 @@ struct HipRT {
 		Scope sc(*this, nm, n);
 		SeedArgs A{f.ix, f.bases, f.base_off, f.lens, f.intv, f.n_intv, f.n_occ, f.scratch, f.list_cap, f.err};
 		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
-		hipLaunchKernelGGL(k_seed_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter);
+		static const int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 16; // lanes that queue up before the slow bookkeeping runs
+		hipLaunchKernelGGL(k_seed_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_batch);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// locate: persistent lanes with wave-level work distribution (hip_fm_coop.h); 32 waves per CU to cover the miss latency
@@ -234,6 +236,21 @@ struct HipRT {
 		if (total <= 0) return;
 		if (sw_simple) {
 			for (int c = 0; c < EXT_CLASSES; ++c) { F fc = f; fc.tasks = f.tasks + (size_t)c * stride; launch_rows(nm, n_class[c], fc, MAX_READ_LEN + 2); }
+			return;
+		}
+		if (total >= ext_merge_below) { // big round: one launch per class, each at the occupancy its own register tiling allows
+			for (int c = 0; c < EXT_CLASSES; ++c) {
+				const int nc = n_class[c];
+				if (nc <= 0) continue;
+				Scope sc(*this, nm, nc);
+				const ExtTask *tk = f.tasks + (size_t)c * stride;
+				const int blocks = coop_blocks(nc);
+				if (c == 0) hipLaunchKernelGGL(k_extend_g16<4>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
+				else if (c == 1) hipLaunchKernelGGL(k_extend_g16<7>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
+				else if (c == 2) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
+				else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
+				ARX_HIP_CHECK(hipGetLastError());
+			}
 			return;
 		}
 		Scope sc(*this, nm, total);

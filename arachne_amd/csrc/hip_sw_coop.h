@@ -353,6 +353,13 @@ __device__ __forceinline__ void extend_class_g16(const IndexView &ix, const uint
 	}
 }
 
+template <int C>
+__global__ void __launch_bounds__(64) k_extend_g16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
+{
+	__shared__ uint8_t target_lds[4][EXT_T_CAP];
+	extend_class_g16<C>(ix, bases, tasks, res, n, blockIdx.x, gridDim.x, target_lds[threadIdx.x >> 4]);
+}
+
 // All query-length classes of a round in one launch: blocks [0, nb.x) take class 0, the next nb.y class 1, ...  Every
 // wavefront runs one tiling, and the classes run side by side (late rounds hold few extensions: launched one class after
 // the other, each launch would cost the latency of a whole DP).

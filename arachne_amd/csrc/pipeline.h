@@ -99,7 +99,9 @@ struct KExtStep {
 		state[r] = st;
 		if (more) {
 			const int c = ext_class(t.qlen);
-			tasks[(size_t)c * task_stride + claim(n_tasks + c)] = t;
+			int at = 0;
+			for (int k = 0; k < EXT_CLASSES; ++k) if (c == k) at = claim(n_tasks + k); // one counter per branch: the compiler folds a wavefront's increments of one address into a single atomic
+			tasks[(size_t)c * task_stride + at] = t;
 			act_out[claim(n_tasks + EXT_CLASSES)] = r;
 		}
 	}

@@ -25,6 +25,8 @@ t = time.time(); b.run(api.STAGE_ALN); t1 = time.time(); b.rfa(po, flags, fetch=
 kt = ref.kernel_times()
 print("wall aln %.1f ms, rfa %.1f ms" % ((t1 - t) * 1e3, (t2 - t1) * 1e3))
 print({k: round(v["ms"], 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])})
+if os.environ.get("ROUNDS_BRIEF"):
+    sys.exit(0)
 rows = [r for r in (l.rstrip("\n").split("\t") for l in open(log)) if len(r) == 3]
 by = collections.defaultdict(list)
 for nm, items, ms in rows:
