@@ -100,6 +100,7 @@ ARX_DEVI uint64_t occ1(const IndexView &ix, uint64_t k, int c)
 
 // bwt_extend (bwt.c:262-274), returning only the child for symbol c -- the SMEM search never looks at the other three.
 // is_back = 1 extends x[0] (k) with the cumulative sizes fixing x[1] (l); is_back = 0 the other way round.
+ARX_DEVI uint64_t sel4(const uint64_t v[4], int c) { return c == 0 ? v[0] : c == 1 ? v[1] : c == 2 ? v[2] : v[3]; } // keeps v[] in registers (a dynamic index would spill it)
 ARX_DEVI Biv extend1(const IndexView &ix, const Biv &ik, int is_back, int c)
 {
 	uint64_t a = is_back ? ik.k : ik.l, b = is_back ? ik.l : ik.k;
@@ -111,8 +112,10 @@ ARX_DEVI Biv extend1(const IndexView &ix, const Biv &ik, int is_back, int c)
 	if (c < 2) x += s2;
 	if (c < 1) x += s1;
 	Biv ok;
-	uint64_t na = ix.L2[c] + 1 + tk[c];
-	ok.s = tl[c] - tk[c];
+	const uint64_t tkc = sel4(tk, c), tlc = sel4(tl, c);
+	const uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+	uint64_t na = l2c + 1 + tkc;
+	ok.s = tlc - tkc;
 	if (is_back) { ok.k = na; ok.l = x; } else { ok.l = na; ok.k = x; }
 	ok.info = 0;
 	return ok;

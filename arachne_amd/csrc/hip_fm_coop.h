@@ -52,14 +52,14 @@ static __global__ void __launch_bounds__(256) k_locate_dyn(IndexView ix, Seed *o
 // SeedLane::advance() runs each lane's bookkeeping up to its next extension, the lanes reconverge on extend1().
 // The read's bases are staged in LDS (4-bit codes, row stride 33 words so that the 64 lanes hit different banks): the
 // search reads one base per extension, which would otherwise be a dependent HBM access in front of the Occ block loads.
-constexpr int SEED_CHUNK = 256, SEED_ROW = 132; // SEED_ROW bytes per lane: 256 bases + pad
+constexpr int SEED_ROW = 132; // bytes per lane: 256 bases + pad
 
 struct SeedArgs {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens;
 	Biv *intv; int32_t *n_intv, *n_occ; Biv *scratch; int list_cap; uint32_t *err;
 };
 
-static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32_t *counter, int batch)
+static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32_t *counter, int batch, int chunk)
 {
 	__shared__ uint8_t q_lds[64 * SEED_ROW];
 	const int lane = threadIdx.x;
@@ -91,10 +91,10 @@ static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32
 			if (idle) {
 				if (pool_next == pool_end && !exhausted) {
 					int base = 0;
-					if (lane == 0) base = atomicAdd(counter, SEED_CHUNK);
+					if (lane == 0) base = atomicAdd(counter, chunk);
 					base = __shfl(base, 0);
 					if (base >= n) { exhausted = true; pool_next = pool_end = n; }
-					else { pool_next = base; pool_end = base + SEED_CHUNK < n ? base + SEED_CHUNK : n; }
+					else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
 				}
 				const int avail = pool_end - pool_next;
 				if (avail > 0) {
