@@ -110,7 +110,7 @@ struct HipRT {
 	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }
 
 	// 8 resident 64-thread blocks per CU give every SIMD two waves of these latency-bound kernels
-	int bpc = getenv("ARX_BPC") ? atoi(getenv("ARX_BPC")) : 12;           // resident 64-lane blocks per CU of the thread-per-item kernels (sizes their per-slot scratch)
+	int bpc = getenv("ARX_BPC") ? atoi(getenv("ARX_BPC")) : 16;           // resident 64-lane blocks per CU of the thread-per-item kernels (sizes their per-slot scratch)
 	int coop_bpc = getenv("ARX_COOP_BPC") ? atoi(getenv("ARX_COOP_BPC")) : 64; // grid cap of the 16-lane DP kernels (no per-slot scratch; grid-stride)
 	int ext_merge_below = getenv("ARX_EXT_MERGE") ? atoi(getenv("ARX_EXT_MERGE")) : 30000; // rounds with fewer extensions run all length classes in one launch
 	int max_blocks() const { return n_cu * bpc; }
