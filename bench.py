@@ -243,14 +243,22 @@ def main():
             if k and k["calls"]:
                 avg_ms = k["ms"] / k["calls"]
                 achieved = ab["seed"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
-                out["roofline"] = dict(kernel="seed (KSeed: SMEM search, bwt_extend/bwt_2occ4)", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
-                                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                # memory-side bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE pass of this command (counters
+                # cannot be read from inside the process); null when no such pass is committed
+                traffic, traffic_src = None, None
+                tf = os.path.join(ROOT, "profiles", "r01", "seed_traffic.json")
+                if os.path.exists(tf):
+                    tj = json.load(open(tf))
+                    traffic = tj["fabric_bytes_per_read"] * reads_per_launch
+                    traffic_src = "profiles/r01/seed_traffic.json"
+                out["roofline"] = dict(kernel="seed (k_seed_dyn: SMEM search, bwt_extend/bwt_2occ4)", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
+                                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_unit="bytes per launch", traffic_source=traffic_src,
                                        algorithmic_bytes_per_read=ab["seed"], reads_per_launch=reads_per_launch, avg_launch_ms=avg_ms)
             kl = ktimes.get("locate")
             if kl and kl["calls"]:
                 avg_ms = kl["ms"] / kl["calls"]
                 ach = ab["locate"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
-                out["roofline_locate"] = dict(kernel="locate (KLocate: bwt_sa LF walk)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                               frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms)
             out["work_per_read"] = ab["counters"]
         except Exception as e:  # the roofline needs the oracle library; never fail the throughput line over it

@@ -7,10 +7,11 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"k_items<arx::(\w+)>|k_block_items<arx::(\w+)>|arx::(k_\w+)|(k_calib_blocks)|rocprim.*?::(\w+_kernel)", name)
-    if not m:
-        return name[:60]
-    return next(g for g in m.groups() if g)
+    for pat in (r"k_items<arx::(\w+)>", r"k_block_items<arx::(\w+)>", r"arx::(k_\w+(?:<\d+>)?)", r"(k_calib_blocks)", r"rocprim.*?::(\w+_kernel)"):
+        m = re.search(pat, name)
+        if m:
+            return m.group(1)
+    return name[:60]
 
 
 def find(d, pat):
