@@ -14,12 +14,21 @@ namespace arx {
 // ------------------------------------------------------------------------------------------------
 // mem_chain2aln (bwamem.c:632-786) as a state machine
 // ------------------------------------------------------------------------------------------------
-enum { PH_PICK = 0, PH_LEFT = 1, PH_RIGHT = 2, PH_DONE = 3 };
+// One state machine per CHAIN.  The reference walks a read's chains one after the other because the "is this seed already
+// explained" test (bwamem.c:671-706) looks at every region found so far.  A region of chain c lies inside c's reference
+// window [rmax0, rmax1) (the extensions never leave it), so it can only contain a seed that lies inside that window: a
+// later chain none of whose seeds does is independent of c and runs side by side with it; one that has such a seed waits
+// until c is finished and then sees c's regions.  The regions of a chain go to the slots of its own seeds; they are
+// concatenated in chain order afterwards (KExtGather), which is the order the reference produces them in.
+enum { PH_PICK = 0, PH_LEFT = 1, PH_RIGHT = 2, PH_DONE = 3, PH_WAIT = 4 };
+enum { EXT_FINISHED = 0, EXT_TASK = 1, EXT_WAITING = 2 };
 
 struct ExtState {
 	int64_t rmax0, rmax1;
 	Reg a;                 // region being built
-	int32_t ci, k, phase, band_try, n_regs, seed, sc0, aw0, aw1, prev, rstart, pad;  // initial state: ci = -1, k = -1, phase = PH_PICK
+	int32_t k, phase, band_try, n_regs, seed, sc0, aw0, aw1, prev, rstart;
+	int32_t done_round;    // 0: running; otherwise the round it finished in (rounds count from 2; 1 = empty chain, finished at set-up)
+	int32_t dep_cursor;    // earlier chains below this index are known not to hold it back
 };
 
 struct SeedKeyLt { // ascending (score<<32 | index) with score == len (bwamem.c:663-665); keys are unique
@@ -52,27 +61,41 @@ ARX_DEV void ext_begin_chain(const IndexView &ix, int l_query, const Chain &c, c
 	st.k = c.n - 1;
 }
 
-// Is seed s (srt position k) already explained by an earlier region of this read?  (bwamem.c:671-706)
-ARX_DEV bool ext_seed_skipped(int l_query, const Chain &c, const Seed *seeds, const int *srt, int k, const Reg *av, int n_av)
+// Does region p explain seed s (the body of the loop at bwamem.c:671-689)?
+ARX_DEVI bool reg_explains_seed(const Reg &p, const Seed &s, int l_query)
 {
+	int64_t rd;
+	int qd, w, max_gap;
+	if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) return false;
+	if (s.len - p.seedlen0 > .1 * l_query) return false;
+	qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+	max_gap = cal_max_gap(qd < rd ? qd : (int)rd);
+	w = max_gap < p.w ? max_gap : p.w;
+	if (qd - rd < w && rd - qd < w) return true;
+	qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+	max_gap = cal_max_gap(qd < rd ? qd : (int)rd);
+	w = max_gap < p.w ? max_gap : p.w;
+	return qd - rd < w && rd - qd < w;
+}
+
+// Is seed s (srt position k of chain ci) already explained by an earlier region of this read?  (bwamem.c:671-706)
+// Earlier regions = those of the earlier chains that finished before this round, and this chain's own.
+ARX_DEV bool ext_seed_skipped(int l_query, const Chain *chains, int ci, const Seed *seeds, const int *srt, int k, const Reg *reg_pool,
+                              const ExtState *states, int round, const Reg *own, int n_own)
+{
+	const Chain &c = chains[ci];
 	const Seed s = seeds[srt[k]];
-	int i;
-	for (i = 0; i < n_av; ++i) {
-		const Reg &p = av[i];
-		int64_t rd;
-		int qd, w, max_gap;
-		if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
-		if (s.len - p.seedlen0 > .1 * l_query) continue;
-		qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
-		max_gap = cal_max_gap(qd < rd ? qd : (int)rd);
-		w = max_gap < p.w ? max_gap : p.w;
-		if (qd - rd < w && rd - qd < w) break;
-		qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-		max_gap = cal_max_gap(qd < rd ? qd : (int)rd);
-		w = max_gap < p.w ? max_gap : p.w;
-		if (qd - rd < w && rd - qd < w) break;
+	bool hit = false;
+	for (int c2 = 0; c2 < ci && !hit; ++c2) {
+		const int dr = states[c2].done_round;
+		if (dr <= 0 || dr >= round) continue; // still running: independent of this chain (see the dependency scan), its regions cannot contain s
+		const Reg *av = reg_pool + chains[c2].seed_off;
+		const int n_av = states[c2].n_regs;
+		for (int i = 0; i < n_av; ++i) if (reg_explains_seed(av[i], s, l_query)) { hit = true; break; }
 	}
-	if (i == n_av) return false;
+	for (int i = 0; i < n_own && !hit; ++i) if (reg_explains_seed(own[i], s, l_query)) hit = true;
+	if (!hit) return false;
+	int i;
 	for (i = k + 1; i < c.n; ++i) { // an extended, overlapping, off-diagonal seed keeps this one alive
 		if (srt[i] < 0) continue;
 		const Seed t = seeds[srt[i]];
@@ -98,16 +121,40 @@ ARX_DEVI void ext_make_task(ExtTask &t, int owner, int read_base, int l_query, c
 	}
 }
 
-// Advance one read until it needs a DP (returns true, task filled) or has no seed left (returns false).
-// chains/seeds/srt/av are this read's slices; res is the result of the task emitted by the previous call.
-ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query, const Chain *chains, int n_chains,
-                      const Seed *seed_pool, int *srt_pool, Reg *av, ExtState &st, const ExtRes &res, ExtTask &task)
+// Set up chain ci of a read (bwamem.c:642-665): window, seed order; empty chains are finished at once.
+ARX_DEV void ext_init_chain(const IndexView &ix, int l_query, const Chain &c, const Seed *seed_pool, int *srt_pool, ExtState &st)
 {
+	st = ExtState();
+	st.k = -1; st.n_regs = 0; st.dep_cursor = 0;
+	if (c.n == 0) { st.phase = PH_DONE; st.done_round = 1; return; }
+	ext_begin_chain(ix, l_query, c, seed_pool + c.seed_off, srt_pool + c.seed_off, st);
+	st.phase = PH_WAIT; st.done_round = 0;
+}
+
+// Advance chain ci until it needs a DP (EXT_TASK, task filled), has to wait for an earlier chain (EXT_WAITING) or has no
+// seed left (EXT_FINISHED).  chains/states: the read's slices; reg_pool/seed_pool/srt_pool: batch pools indexed by
+// Chain::seed_off; res: the result of the task emitted by the previous call; round: number of this step (>= 2).
+ARX_DEV int ext_step(const IndexView &ix, int owner, int read_base, int l_query, const Chain *chains, int ci,
+                     const Seed *seed_pool, int *srt_pool, Reg *reg_pool, const ExtState *states, int round, ExtState &st, const ExtRes &res, ExtTask &task)
+{
+	const Chain *c = &chains[ci];
+	const Seed *seeds = seed_pool + c->seed_off;
+	int *srt = srt_pool + c->seed_off;
+	Reg *av = reg_pool + c->seed_off;
+	if (st.phase == PH_DONE) return EXT_FINISHED;
+	if (st.phase == PH_WAIT) { // an earlier, unfinished chain whose window holds one of this chain's seeds?
+		for (int c2 = st.dep_cursor; c2 < ci; ++c2) {
+			const int dr = states[c2].done_round;
+			if (dr > 0 && dr < round) continue;
+			const int64_t w0 = states[c2].rmax0, w1 = states[c2].rmax1;
+			bool inside = false;
+			for (int i = 0; i < c->n && !inside; ++i) inside = seeds[i].rbeg >= w0 && seeds[i].rbeg + seeds[i].len <= w1;
+			if (inside) { st.dep_cursor = c2; return EXT_WAITING; }
+		}
+		st.dep_cursor = ci;
+		st.phase = PH_PICK;
+	}
 	for (;;) {
-		if (st.phase == PH_DONE) return false;
-		const Chain *c = (st.ci >= 0 && st.ci < n_chains) ? &chains[st.ci] : 0;
-		const Seed *seeds = c ? seed_pool + c->seed_off : 0;
-		int *srt = c ? srt_pool + c->seed_off : 0;
 		if (st.phase == PH_LEFT) {
 			const Seed s = seeds[st.seed];
 			Reg &a = st.a;
@@ -116,7 +163,7 @@ ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query
 			if (!(a.score == st.prev || res.max_off < (st.aw0 >> 1) + (st.aw0 >> 2)) && st.band_try + 1 < OPT_MAX_BAND_TRY) {
 				st.prev = a.score; ++st.band_try;
 				ext_make_task(task, owner, read_base, l_query, s, st, true);
-				return true;
+				return EXT_TASK;
 			}
 			if (res.gscore <= 0 || res.gscore <= a.score - OPT_PEN_CLIP5) { a.qb = s.qbeg - res.qle; a.rb = s.rbeg - res.tle; a.truesc = a.score; }
 			else { a.qb = 0; a.rb = s.rbeg - res.gtle; a.truesc = res.gscore; }
@@ -130,7 +177,7 @@ ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query
 				if (s.qbeg + s.len != l_query) {
 					st.sc0 = a.score; st.prev = a.score; st.band_try = 0; st.rstart = 1;
 					ext_make_task(task, owner, read_base, l_query, s, st, false);
-					return true;
+					return EXT_TASK;
 				}
 				a.qe = l_query; a.re = s.rbeg + s.len;
 				finish = true;
@@ -140,7 +187,7 @@ ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query
 				if (!(a.score == st.prev || res.max_off < (st.aw1 >> 1) + (st.aw1 >> 2)) && st.band_try + 1 < OPT_MAX_BAND_TRY) {
 					st.prev = a.score; ++st.band_try;
 					ext_make_task(task, owner, read_base, l_query, s, st, false);
-					return true;
+					return EXT_TASK;
 				}
 				int qe = s.qbeg + s.len;
 				if (res.gscore <= 0 || res.gscore <= a.score - OPT_PEN_CLIP3) { a.qe = qe + res.qle; a.re = s.rbeg + s.len + res.tle; a.truesc += a.score - st.sc0; }
@@ -162,14 +209,8 @@ ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query
 			}
 		}
 		// PH_PICK
-		if (st.k < 0) { // next chain
-			++st.ci;
-			if (st.ci >= n_chains) { st.phase = PH_DONE; return false; }
-			c = &chains[st.ci]; seeds = seed_pool + c->seed_off; srt = srt_pool + c->seed_off;
-			if (c->n == 0) { st.k = -1; continue; }
-			ext_begin_chain(ix, l_query, *c, seeds, srt, st);
-		}
-		if (ext_seed_skipped(l_query, *c, seeds, srt, st.k, av, st.n_regs)) { srt[st.k] = -1; --st.k; continue; }
+		if (st.k < 0) { st.phase = PH_DONE; st.done_round = round; return EXT_FINISHED; }
+		if (ext_seed_skipped(l_query, chains, ci, seeds, srt, st.k, reg_pool, states, round, av, st.n_regs)) { srt[st.k] = -1; --st.k; continue; }
 		{
 			st.seed = srt[st.k];
 			const Seed s = seeds[st.seed];
@@ -183,7 +224,7 @@ ARX_DEV bool ext_step(const IndexView &ix, int owner, int read_base, int l_query
 			if (s.qbeg) {
 				st.phase = PH_LEFT; st.band_try = 0; st.prev = -1;
 				ext_make_task(task, owner, read_base, l_query, s, st, true);
-				return true;
+				return EXT_TASK;
 			}
 			a.score = a.truesc = s.len * OPT_A; a.qb = 0; a.rb = s.rbeg;
 			st.phase = PH_RIGHT; st.rstart = 0;

@@ -81,31 +81,60 @@ struct KChain {
 	}
 };
 
+// per read: set up one state machine per chain (chain gid = chain_off[read] + index) and remember the chain's read
+struct KExtInit {
+	IndexView ix; const int32_t *lens, *occ_off, *n_chain, *chain_off; const Chain *chains; const Seed *seeds; int32_t *srt; ExtState *state; int32_t *chain_read;
+	ARX_DEV void operator()(int r, int) const
+	{
+		const int g0 = occ_off[r], c0 = chain_off[r];
+		for (int ci = 0; ci < n_chain[r]; ++ci) {
+			ExtState st;
+			ext_init_chain(ix, lens[r], chains[g0 + ci], seeds, srt, st);
+			state[c0 + ci] = st;
+			chain_read[c0 + ci] = r;
+		}
+	}
+};
+
 struct KExtStep {
-	IndexView ix; const int32_t *base_off, *lens, *occ_off, *n_chain; const Chain *chains; const Seed *seeds; int32_t *srt; Reg *regs;
-	ExtState *state; const ExtRes *res; ExtTask *tasks; int32_t *n_tasks; int first;
+	IndexView ix; const int32_t *base_off, *lens, *occ_off, *chain_off, *chain_read; const Chain *chains; const Seed *seeds; int32_t *srt; Reg *regs;
+	ExtState *state; const ExtRes *res; ExtTask *tasks; int32_t *n_tasks; int round;
 	int task_stride;                              // tasks + c * task_stride: the list of length class c, n_tasks[c] its length
-	const int32_t *act_in; int32_t *act_out;      // reads still extending (null in the first round: all); n_tasks[EXT_CLASSES] counts act_out
+	const int32_t *act_in; int32_t *act_out;      // chains still extending or waiting (null in the first round: all); n_tasks[EXT_CLASSES] counts act_out
 	ARX_DEV void operator()(int item, int) const
 	{
-		const int r = act_in ? act_in[item] : item;
-		ExtState st;
-		if (first) { st = ExtState(); st.ci = -1; st.k = -1; st.phase = PH_PICK; st.n_regs = 0; }
-		else { st = state[r]; if (st.phase == PH_DONE) return; }
+		const int gid = act_in ? act_in[item] : item;
+		ExtState st = state[gid];
+		if (st.phase == PH_DONE) return;
+		const int r = chain_read[gid], c0 = chain_off[r], g0 = occ_off[r];
 		ExtTask t;
-		const int g0 = occ_off[r];
-		ExtRes rs = first ? ExtRes() : res[r];
-		bool more = ext_step(ix, r, base_off[r], lens[r], chains + g0, n_chain[r], seeds, srt, regs + g0, st, rs, t);
-		state[r] = st;
-		if (more) {
+		const ExtRes rs = res[gid]; // only read by a chain that queued a DP in the previous round
+		const int what = ext_step(ix, gid, base_off[r], lens[r], chains + g0, gid - c0, seeds, srt, regs, state + c0, round, st, rs, t);
+		state[gid] = st;
+		if (what == EXT_TASK) {
 			const int c = ext_class(t.qlen);
 			int at = 0;
 			for (int k = 0; k < EXT_CLASSES; ++k) if (c == k) at = claim(n_tasks + k); // one counter per branch: the compiler folds a wavefront's increments of one address into a single atomic
 			tasks[(size_t)c * task_stride + at] = t;
-			act_out[claim(n_tasks + EXT_CLASSES)] = r;
 		}
+		if (what != EXT_FINISHED) act_out[claim(n_tasks + EXT_CLASSES)] = gid;
 	}
 	static ARX_DEVI int claim(int32_t *ctr) { return ARX_ATOMIC_INC(ctr); }
+};
+
+// per read: its chains' regions in chain order -> the read's region list (the order mem_chain2aln appends them in)
+struct KExtGather {
+	const int32_t *occ_off, *n_chain, *chain_off; const Chain *chains; const ExtState *state; const Reg *pool; Reg *regs; int32_t *n_ext;
+	ARX_DEV void operator()(int r, int) const
+	{
+		const int g0 = occ_off[r], c0 = chain_off[r];
+		int n = 0;
+		for (int ci = 0; ci < n_chain[r]; ++ci) {
+			const Reg *src = pool + chains[g0 + ci].seed_off;
+			for (int i = 0; i < state[c0 + ci].n_regs; ++i) regs[g0 + n++] = src[i];
+		}
+		n_ext[r] = n;
+	}
 };
 
 struct KExtend {
@@ -118,12 +147,12 @@ struct KExtend {
 };
 
 struct KDedup {
-	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const ExtState *state; Reg *regs, *tmp; int32_t *idx;
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const int32_t *n_ext; Reg *regs, *tmp; int32_t *idx;
 	int32_t *eh; int eh_words; int32_t *n_core; int dbg;
 	ARX_DEV void operator()(int r, int slot) const
 	{
 		const int g0 = occ_off[r];
-		int n = state[r].n_regs;
+		int n = n_ext[r];
 		if (dbg & 4) { n_core[r] = n; return; }
 		if (dbg & 2) { RegReLt lt1; lt1.r = regs + g0; permute_regs(n, regs + g0, tmp + g0, idx + g0, lt1); n_core[r] = n; return; }
 		n = sort_dedup_patch(ix, (dbg & 1) ? (const uint8_t *)0 : bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
@@ -331,32 +360,43 @@ public:
 	{
 		const int R = b.n_reads; const size_t T = (size_t)w.T + 1; const int slots = rt.max_slots();
 		w.srt = rt.template alloc<int32_t>(T); w.regs = rt.template alloc<Reg>(T); w.rtmp = rt.template alloc<Reg>(T); w.idx = rt.template alloc<int32_t>(T);
-		w.est = rt.template alloc<ExtState>(R + 1); w.etask = rt.template alloc<ExtTask>((size_t)EXT_CLASSES * (R + 1)); w.eres = rt.template alloc<ExtRes>(R + 1);
-		int32_t *act[2] = { rt.template alloc<int32_t>(R + 1), rt.template alloc<int32_t>(R + 1) };
-		int32_t *ecnt = rt.template alloc<int32_t>(EXT_CLASSES + 1);
-		int n_act = R;
 		w.n_core = rt.template alloc<int32_t>(R + 1);
 		const int eh_words = 2 * (b.max_len + 2);
 		w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
-		for (int round = 0;; ++round) {
+		// one state machine per chain (dev_regs.h): chain gids by a scan of the per-read chain counts
+		int32_t *chain_off = rt.template alloc<int32_t>(R + 2);
+		const int NCH = (int)rt.exclusive_scan(w.n_chain, chain_off, R);
+		w.est = rt.template alloc<ExtState>((size_t)NCH + 1); w.eres = rt.template alloc<ExtRes>((size_t)NCH + 1);
+		w.etask = rt.template alloc<ExtTask>((size_t)EXT_CLASSES * (NCH + 1));
+		int32_t *chain_read = rt.template alloc<int32_t>((size_t)NCH + 1);
+		int32_t *act[2] = { rt.template alloc<int32_t>((size_t)NCH + 1), rt.template alloc<int32_t>((size_t)NCH + 1) };
+		int32_t *ecnt = rt.template alloc<int32_t>(EXT_CLASSES + 1);
+		int32_t *n_ext = rt.template alloc<int32_t>(R + 1);
+		Reg *pool = w.rtmp; // the chains' regions while they are extended; gathered into w.regs in chain order afterwards
+		KExtInit ki{ix, b.lens, w.occ_off, w.n_chain, chain_off, w.cout, w.sout, w.srt, w.est, chain_read};
+		rt.launch("ext_init", R, ki);
+		int n_act = NCH;
+		for (int round = 2; n_act > 0; ++round) {
 			rt.memset0(ecnt, 4 * (EXT_CLASSES + 1));
-			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, w.n_chain, w.cout, w.sout, w.srt, w.regs, w.est, w.eres, w.etask, ecnt, round == 0,
-			            R + 1, round == 0 ? nullptr : act[round & 1], act[(round + 1) & 1]};
+			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, chain_off, chain_read, w.cout, w.sout, w.srt, pool, w.est, w.eres, w.etask, ecnt, round,
+			            NCH + 1, round == 2 ? nullptr : act[round & 1], act[(round + 1) & 1]};
 			rt.launch("ext_step", n_act, ks);
 			int32_t cnt[EXT_CLASSES + 1];
 			rt.d2h(cnt, ecnt, 4 * (EXT_CLASSES + 1));
-			int nt = cnt[EXT_CLASSES];
-			n_act = nt; // a read that queued an extension is the only kind that comes back
-			if (trace) { fprintf(stderr, "[arx] ext round %d: %d tasks\n", round, nt); fflush(stderr); }
-			if (nt == 0) break;
-			if (round > w.T + R + 8) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; } // cannot happen: every round retires a DP
+			n_act = cnt[EXT_CLASSES];
+			int nt = 0;
+			for (int c = 0; c < EXT_CLASSES; ++c) nt += cnt[c];
+			if (trace) { fprintf(stderr, "[arx] ext round %d: %d chains active, %d DPs\n", round, n_act, nt); fflush(stderr); }
+			if (round > w.T + R + 8) { uint32_t e = ERR_INTERNAL; rt.h2d(w.err, &e, 4); break; } // cannot happen: every round retires a DP or a chain
+			if (nt == 0) continue;
 			out.n_ext_tasks += nt; ++out.ext_rounds;
 			KExtend ke{ix, b.bases, w.etask, w.eres};
-			rt.run_extend("extend", cnt, R + 1, ke);
-			if (trace) { rt.sync(); fprintf(stderr, "[arx]   extend kernel done\n"); fflush(stderr); }
+			rt.run_extend("extend", cnt, NCH + 1, ke);
 		}
+		KExtGather kg{w.occ_off, w.n_chain, chain_off, w.cout, w.est, pool, w.regs, n_ext};
+		rt.launch("ext_gather", R, kg);
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
-		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, w.est, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, getenv("ARX_DEDUP_DBG") ? atoi(getenv("ARX_DEDUP_DBG")) : 0};
+		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, getenv("ARX_DEDUP_DBG") ? atoi(getenv("ARX_DEDUP_DBG")) : 0};
 		rt.launch_cold("dedup", R, kd);
 	}
 
