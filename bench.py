@@ -124,11 +124,12 @@ def main():
     ap.add_argument("--barcodes", type=int, default=1000)
     ap.add_argument("--pairs-per-barcode", type=int, default=1000)
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
-    ap.add_argument("--chunk-pairs", type=int, default=350_000, help="pairs per device batch inside one step")
-    ap.add_argument("--streams", type=int, default=3, help="device batches in flight (one HIP stream + host thread each)")
+    ap.add_argument("--chunk-pairs", type=int, default=500_000, help="pairs per device batch inside one step")
+    ap.add_argument("--streams", type=int, default=2, help="device batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
+    ap.add_argument("--overlap-seed", action="store_true", help="(diagnostics) no separate seeding phase: every batch runs start to end on its stream")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
     ap.add_argument("--lib", default=None, help="(dry runs of this script only) alternative library exporting the C ABI")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for the CPU dry run of the sharding logic)")
@@ -192,8 +193,9 @@ def main():
     def step():
         # phase 1: the HBM-bound seeding + locate kernels, one batch after the other (they fill the chip on their own and
         # their HIP-event time is then the un-overlapped kernel time the roofline is computed from)
-        for b in batches:
-            b.run(api.STAGE_SEED)
+        if not args.overlap_seed:
+            for b in batches:
+                b.run(api.STAGE_SEED)
         # phase 2: chain .. CIGAR resume from there, then the per-barcode RFA placement + MAPQ; all batches in flight
         def rest(b):
             b.run(api.STAGE_ALN)
