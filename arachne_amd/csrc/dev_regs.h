@@ -346,6 +346,7 @@ ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, R
 struct ResState {
 	int64_t rb, re;        // clamped window of the pending SW
 	uint64_t spec_mask;    // bit k: the k-th anchor above the score threshold had its SW queued ahead
+	int32_t clean[2];      // clean[o]: read o's list is a fixed point of mem_sort_dedup_patch (see matesw_apply)
 	int32_t e, i, num, n_snap, best[2], phase, spec_off; // phase 0: replaying, 1: waiting for a single SW, 2: finished, 3: loop `e` not enumerated yet
 };
 struct SwTask { int64_t rb, re; int32_t pair, o, slot, pad; };
@@ -360,10 +361,18 @@ ARX_DEVI int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) // 
 }
 
 // Insert the rescued region and re-sort (bwamem_pair.c:150-176).  ma has room for one more entry.
-ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Res &aln, int64_t rb, Reg *ma, int n_ma, Reg *tmp, int *idx)
+// mem_sort_dedup_patch runs after every SW of the loop, also after one that added nothing (bwamem_pair.c:175).  Without
+// patching (query = 0 here) it is idempotent on its own output: the survivors of the redundancy pass were all compared with
+// each other and found distinct (the overlap test does not depend on which of two equal-`re` regions comes first), the final
+// order is the strict order by (score, rb, qb), and n_comp is 1 throughout.  So once the list has been through it (*clean)
+// and until something is inserted again, the call is skipped.
+ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Res &aln, int64_t rb, Reg *ma, int n_ma, Reg *tmp, int *idx, int32_t *clean)
 {
 	const int64_t l_pac = ix.l_pac;
-	if (aln.score >= OPT_MIN_SEED_LEN && aln.qb >= 0) { // is_rev == 1 for the FR orientation
+	const bool inserts = aln.score >= OPT_MIN_SEED_LEN && aln.qb >= 0;
+	if (!inserts && *clean) return n_ma;
+	*clean = 1;
+	if (inserts) { // is_rev == 1 for the FR orientation
 		Reg b = Reg();
 		b.rb = b.re = 0; b.truesc = b.sub = b.alt_sc = b.sub_n = b.w = b.secondary_all = b.seedlen0 = b.n_comp = 0; b.frac_rep = 0.f; b.pad = 0;
 		b.rid = a.rid;
@@ -449,7 +458,7 @@ ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *c
 		}
 		const int e = st.e, o = 1 - e;
 		if (st.phase == 1) { // the single SW came back: ma = the other read's list
-			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], sres[emit.single_slot], st.rb, regs[o], *n_regs[o], tmp[o], idx[o]);
+			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], sres[emit.single_slot], st.rb, regs[o], *n_regs[o], tmp[o], idx[o], &st.clean[o]);
 			st.phase = 0; ++st.i;
 		}
 		if (st.i >= st.n_snap || st.num >= MAX_RESCUE || lens2[o] <= 0) {
@@ -465,7 +474,7 @@ ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *c
 		if (!rescue_window(ix, a, lens2[o], &rb, &re)) { ++st.i; continue; } // nothing aligned: ma stays as it is
 		if (st.spec_mask >> k & 1) {
 			const int slot = st.spec_off + __builtin_popcountll(st.spec_mask & (((uint64_t)1 << k) - 1));
-			*n_regs[o] = matesw_apply(ix, a, lens2[o], sres[slot], rb, regs[o], *n_regs[o], tmp[o], idx[o]);
+			*n_regs[o] = matesw_apply(ix, a, lens2[o], sres[slot], rb, regs[o], *n_regs[o], tmp[o], idx[o], &st.clean[o]);
 			++st.i;
 			continue;
 		}
