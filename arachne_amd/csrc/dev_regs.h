@@ -9,6 +9,15 @@
 #include "arx_dev.h"
 #include "dev_sw.h"
 
+#ifndef ARX_STAT_RESCUE
+#define ARX_STAT_RESCUE(pair, n, inserts, clean) ((void)0) // the host test double can count rescue work here
+#endif
+#ifndef ARX_RESCUE_FAST   // the host test double can switch dedup_insert() off, or check it against the general path
+#define ARX_RESCUE_FAST 1
+#define ARX_RESCUE_CROSSCHECK_BEGIN(ma, n, b) ((void)0)
+#define ARX_RESCUE_CROSSCHECK_END(ix, ma, m) ((void)0)
+#endif
+
 namespace arx {
 
 // ------------------------------------------------------------------------------------------------
@@ -360,18 +369,102 @@ ARX_DEVI int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) // 
 	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
 }
 
+// The redundancy test of mem_sort_dedup_patch (bwamem.c:452-459) for p = the region later in `re` order, q = the earlier one
+ARX_DEVI bool regs_redundant(const Reg &p, const Reg &q)
+{
+	const int64_t orr = q.re - p.rb;
+	const int64_t oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+	const int64_t mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+	const int64_t mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+	return (float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq;
+}
+
+// mem_sort_dedup_patch(list + b) when `list` (n >= 1 regions) is already a fixed point of it (sorted by (score desc, rb,
+// qb), pairwise non-redundant, no patching since query = 0): only pairs with b can interact, so the two sorts and the
+// quadratic pass collapse to one scan.  In `re` order b first meets the earlier regions of its contig within
+// max_chain_gap, latest first (a redundant one with the smaller score goes; if that is b the scan stops), then every later
+// region meets b the same way.  Regions of one contig are contiguous in `re` order, which makes the set of regions b meets
+// independent of the others.  Returns the new length, or -1 when the outcome would depend on how introsort orders equal
+// keys (a region with the same `re`, or the same (score, rb, qb)): the caller then takes the general path.
+ARX_DEV int dedup_insert(const Reg &b_in, Reg *ma, int n, Reg *tmp, int *idx)
+{
+	Reg b = b_in;
+	b.n_comp = 1;
+	for (int i = 0; i < n; ++i) {
+		if (ma[i].re == b.re) return -1;
+		if (ma[i].score == b.score && ma[i].rb == b.rb && ma[i].qb == b.qb) return -1;
+	}
+	// earlier regions b meets, by decreasing re (insertion sort of the few candidates into idx)
+	int nv = 0;
+	for (int i = 0; i < n; ++i) {
+		const Reg &q = ma[i];
+		if (q.re < b.re && q.rid == b.rid && b.rb < q.re + OPT_MAX_CHAIN_GAP) {
+			int at = nv++;
+			while (at > 0 && ma[idx[at - 1]].re < q.re) { idx[at] = idx[at - 1]; --at; }
+			idx[at] = i;
+		}
+	}
+	bool b_gone = false;
+	int n_gone = 0;
+	for (int t = 0; t < nv && !b_gone; ++t) {
+		Reg &q = ma[idx[t]];
+		if (!regs_redundant(b, q)) continue;
+		if (b.score < q.score) b_gone = true;
+		else { q.qe = q.qb; ++n_gone; }
+	}
+	// later regions meet b, by increasing re; once b is gone nothing else can change
+	if (!b_gone) {
+		nv = 0;
+		for (int i = 0; i < n; ++i) {
+			const Reg &p = ma[i];
+			if (p.re > b.re && p.rid == b.rid && p.rb < b.re + OPT_MAX_CHAIN_GAP) {
+				int at = nv++;
+				while (at > 0 && ma[idx[at - 1]].re > p.re) { idx[at] = idx[at - 1]; --at; }
+				idx[at] = i;
+			}
+		}
+		for (int t = 0; t < nv && !b_gone; ++t) {
+			Reg &p = ma[idx[t]];
+			if (!regs_redundant(p, b)) continue;
+			if (p.score < b.score) { p.qe = p.qb; ++n_gone; }
+			else b_gone = true;
+		}
+	}
+	// survivors in the final order: the old ones keep theirs, b goes in front of the first one that sorts after it
+	if (n_gone == 0) {
+		for (int i = 0; i < n; ++i) ma[i].n_comp = 1;
+		if (b_gone) return n;
+		int at = 0;
+		while (at < n && (ma[at].score > b.score || (ma[at].score == b.score && (ma[at].rb < b.rb || (ma[at].rb == b.rb && ma[at].qb < b.qb))))) ++at;
+		for (int i = n; i > at; --i) ma[i] = ma[i - 1];
+		ma[at] = b;
+		return n + 1;
+	}
+	int m = 0;
+	bool placed = b_gone;
+	for (int i = 0; i < n; ++i) {
+		const Reg &x = ma[i];
+		if (!(x.qe > x.qb)) continue;
+		if (!placed && !(x.score > b.score || (x.score == b.score && (x.rb < b.rb || (x.rb == b.rb && x.qb < b.qb))))) { tmp[m++] = b; placed = true; }
+		tmp[m] = x; tmp[m].n_comp = 1; ++m;
+	}
+	if (!placed) tmp[m++] = b;
+	for (int i = 0; i < m; ++i) ma[i] = tmp[i];
+	return m;
+}
+
 // Insert the rescued region and re-sort (bwamem_pair.c:150-176).  ma has room for one more entry.
 // mem_sort_dedup_patch runs after every SW of the loop, also after one that added nothing (bwamem_pair.c:175).  Without
 // patching (query = 0 here) it is idempotent on its own output: the survivors of the redundancy pass were all compared with
 // each other and found distinct (the overlap test does not depend on which of two equal-`re` regions comes first), the final
 // order is the strict order by (score, rb, qb), and n_comp is 1 throughout.  So once the list has been through it (*clean)
-// and until something is inserted again, the call is skipped.
+// and until something is inserted again the call is skipped, and an insertion into such a list takes dedup_insert().
 ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Res &aln, int64_t rb, Reg *ma, int n_ma, Reg *tmp, int *idx, int32_t *clean)
 {
 	const int64_t l_pac = ix.l_pac;
 	const bool inserts = aln.score >= OPT_MIN_SEED_LEN && aln.qb >= 0;
+	ARX_STAT_RESCUE(pair_id_for_stats, n_ma, inserts, *clean);
 	if (!inserts && *clean) return n_ma;
-	*clean = 1;
 	if (inserts) { // is_rev == 1 for the FR orientation
 		Reg b = Reg();
 		b.rb = b.re = 0; b.truesc = b.sub = b.alt_sc = b.sub_n = b.w = b.secondary_all = b.seedlen0 = b.n_comp = 0; b.frac_rep = 0.f; b.pad = 0;
@@ -385,6 +478,12 @@ ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Re
 		b.csub = aln.score2;
 		b.secondary = -1;
 		b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+		if (*clean == 2 && n_ma >= 1 && ARX_RESCUE_FAST) { // the list went through a full pass with at least two regions
+			ARX_RESCUE_CROSSCHECK_BEGIN(ma, n_ma, b);
+			const int m = dedup_insert(b, ma, n_ma, tmp, idx);
+			ARX_RESCUE_CROSSCHECK_END(ix, ma, m);
+			if (m >= 0) return m;
+		}
 		int i, at;
 		++n_ma;
 		for (i = 0; i < n_ma - 1; ++i) if (ma[i].score < b.score) break;
@@ -392,6 +491,7 @@ ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Re
 		for (i = n_ma - 1; i > at; --i) ma[i] = ma[i - 1];
 		ma[at] = b;
 	}
+	*clean = n_ma >= 2 ? 2 : 1; // with fewer than two regions the pass returns at once and leaves n_comp as it is
 	return sort_dedup_patch(ix, 0, n_ma, ma, tmp, idx, 0);
 }
 

@@ -24,6 +24,23 @@
 #define ARX_ATOMIC_MAX64(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 #define ARX_LOAD_SHARED(p) (*(p))
 static inline int sim_fetch_add(int32_t *p, int v) { int o = *p; *p += v; return o; }
+static long sim_rescue_fast_hits = 0, sim_rescue_fast_fallbacks = 0;
+static long sim_rescue_calls = 0, sim_rescue_ins = 0, sim_rescue_skipped = 0, sim_rescue_nsum = 0, sim_rescue_nmax = 0, sim_rescue_n2sum = 0;
+static void sim_stat_rescue(int n, bool ins, int clean)
+{
+	++sim_rescue_calls; sim_rescue_ins += ins; sim_rescue_skipped += (!ins && clean); sim_rescue_nsum += n; sim_rescue_n2sum += (long)n * n; if (n > sim_rescue_nmax) sim_rescue_nmax = n;
+}
+struct SimStatPrinter { ~SimStatPrinter() { if (getenv("ARX_RESCUE_STATS")) fprintf(stderr, "[sim] rescue applies %ld, inserted %ld, dedup skipped %ld, mean n %.1f, mean n^2 %.1f, max n %ld; fast inserts %ld, fallbacks %ld\n", sim_rescue_calls, sim_rescue_ins, sim_rescue_skipped, sim_rescue_calls ? (double)sim_rescue_nsum / sim_rescue_calls : 0.0, sim_rescue_calls ? (double)sim_rescue_n2sum / sim_rescue_calls : 0.0, sim_rescue_nmax, sim_rescue_fast_hits, sim_rescue_fast_fallbacks); } } sim_stat_printer;
+#define ARX_STAT_RESCUE(pair, n, inserts, clean) sim_stat_rescue((n), (inserts), (clean))
+// ARX_RESCUE_FAST=0 switches dedup_insert() off; ARX_RESCUE_CHECK=1 runs the general path next to it on a copy and aborts on any difference
+static int sim_rescue_fast_f() { const char *e = getenv("ARX_RESCUE_FAST"); return e ? atoi(e) : 1; }
+static int sim_rescue_check_f() { const char *e = getenv("ARX_RESCUE_CHECK"); return e ? atoi(e) : 0; }
+#define ARX_RESCUE_FAST sim_rescue_fast_f()
+#define ARX_RESCUE_CROSSCHECK_BEGIN(ma, n, b) const int sim_rescue_check = sim_rescue_check_f(); std::vector<Reg> chk_(ma, ma + (n)); if (sim_rescue_check) { int at_ = 0; while (at_ < (n) && !(chk_[at_].score < (b).score)) ++at_; chk_.insert(chk_.begin() + at_, (b)); }
+#define ARX_RESCUE_CROSSCHECK_END(ix, ma, m) do { if ((m) >= 0) ++sim_rescue_fast_hits; else ++sim_rescue_fast_fallbacks; if (sim_rescue_check && (m) >= 0) { \
+		std::vector<Reg> t_(chk_.size() + 1); std::vector<int> i_(chk_.size() + 1); \
+		const int m2_ = sort_dedup_patch(ix, 0, (int)chk_.size(), chk_.data(), t_.data(), i_.data(), 0); \
+		if (m2_ != (m) || memcmp(chk_.data(), (ma), sizeof(Reg) * (size_t)m2_)) { fprintf(stderr, "[sim] dedup_insert differs from mem_sort_dedup_patch: %d vs %d regions\n", (m), m2_); abort(); } } } while (0)
 #include "../../arachne_amd/csrc/arx_dev.h"
 
 #include <algorithm>

@@ -56,6 +56,18 @@ def test_rescue_single_sw_path(env, monkeypatch):
     parity.check_final(dev, gold)
 
 
+@pytest.mark.parametrize("mode", ["check", "off"])
+def test_rescue_incremental_dedup(env, monkeypatch, mode):
+    """Inserting a rescued region into a list that is already a fixed point of mem_sort_dedup_patch takes a one-scan path
+    (dev_regs.h dedup_insert).  check: the host double runs the general path next to it on a copy and aborts on any
+    difference; off: the general path alone must give the same final result."""
+    z, ref, o = env
+    monkeypatch.setenv("ARX_RESCUE_CHECK" if mode == "check" else "ARX_RESCUE_FAST", "1" if mode == "check" else "0")
+    dev = ref.mem_mate_sw(z["reads"], z["lens"])
+    gold = dict(reg_off=z["pair_reg_off"], regs=z["pair_regs"], alns=z["pair_alns"], cigars=z["pair_cigars"])
+    parity.check_final(dev, gold)
+
+
 def test_ragged_and_degenerate_reads(env):
     z, ref, o = env
     rows = [z["reads"][i] for i in range(40)]
