@@ -255,9 +255,6 @@ struct RegScoreLt {
 };
 
 template <class LT>
-#ifdef ARX_OPTNONE_PERMUTE
-__attribute__((optnone, noinline))
-#endif
 ARX_DEV void permute_regs(int n, Reg *a, Reg *tmp, int *idx, LT lt)
 {
 	for (int i = 0; i < n; ++i) idx[i] = i;
@@ -289,9 +286,6 @@ ARX_DEV int patch_reg(const IndexView &ix, const uint8_t *query, const Reg &a, c
 	return score;
 }
 
-#ifdef ARX_OPTNONE_DEDUP
-__attribute__((optnone, noinline))
-#endif
 ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, Reg *a, Reg *tmp, int *idx, int32_t *eh)
 {
 	int m, i, j;

@@ -148,14 +148,12 @@ struct KExtend {
 
 struct KDedup {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const int32_t *n_ext; Reg *regs, *tmp; int32_t *idx;
-	int32_t *eh; int eh_words; int32_t *n_core; int dbg;
+	int32_t *eh; int eh_words; int32_t *n_core;
 	ARX_DEV void operator()(int r, int slot) const
 	{
 		const int g0 = occ_off[r];
 		int n = n_ext[r];
-		if (dbg & 4) { n_core[r] = n; return; }
-		if (dbg & 2) { RegReLt lt1; lt1.r = regs + g0; permute_regs(n, regs + g0, tmp + g0, idx + g0, lt1); n_core[r] = n; return; }
-		n = sort_dedup_patch(ix, (dbg & 1) ? (const uint8_t *)0 : bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
+		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
 		for (int i = 0; i < n; ++i) { Reg &p = regs[g0 + i]; if (p.rid >= 0 && ix.ann_alt[p.rid]) p.is_alt = 1; }
 		n_core[r] = n;
 	}
@@ -396,7 +394,7 @@ public:
 		KExtGather kg{w.occ_off, w.n_chain, chain_off, w.cout, w.est, pool, w.regs, n_ext};
 		rt.launch("ext_gather", R, kg);
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
-		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, getenv("ARX_DEDUP_DBG") ? atoi(getenv("ARX_DEDUP_DBG")) : 0};
+		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core};
 		rt.launch_cold("dedup", R, kd);
 	}
 
