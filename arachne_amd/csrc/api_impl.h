@@ -43,7 +43,12 @@ template <class RT> struct Context {
 		e = load_index(prefix, hix);
 		if (!e.empty()) return e;
 		auto up = [&](const void *src, size_t bytes) { void *d = rt.template palloc<uint8_t>(bytes + 64); rt.h2d(d, src, bytes); dev_index.push_back(d); return d; };
-		ix.bwt = (const uint32_t *)up(hix.bwt.data(), hix.bwt.size() * 4);
+		{ // the Occ blocks go to HBM in the checkpointed layout of dev_fm.h (the files keep BWA's)
+			std::vector<uint32_t> packed(hix.bwt);
+			packed.resize((packed.size() + 15) / 16 * 16, 0);
+			for (size_t b = 0; b + 16 <= packed.size(); b += 16) occ_repack_block(packed.data() + b);
+			ix.bwt = (const uint32_t *)up(packed.data(), packed.size() * 4);
+		}
 		ix.sa = (const uint64_t *)up(hix.sa.data(), hix.sa.size() * 8);
 		ix.pac = (const uint8_t *)up(hix.pac.data(), hix.pac.size());
 		ix.ann_off = (const int64_t *)up(hix.ann_off.data(), hix.ann_off.size() * 8);

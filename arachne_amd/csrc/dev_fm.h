@@ -6,56 +6,66 @@
 
 namespace arx {
 
-// ---- Occ block arithmetic.  A block is 64 bytes: 4 x u64 cumulative counts, then 128 symbols as 8 x u32 (16 symbols
-// each, most significant first).  Two words are fused into one u64 (first word in the high half) so that symbol i of the
-// pair sits at bits 63-2i..62-2i; counting is branch-free: a keep-mask derived from n selects the first n symbols.
-struct OccBlock { uint64_t cum[4]; uint64_t w[4]; };
+// ---- Occ block arithmetic.  The index files keep BWA's interleaved layout (per 128 symbols: 4 x u64 cumulative counts,
+// then 8 x u32 of 16 symbols each, most significant first).  In HBM the same 64 bytes are re-packed when the index is
+// opened (occ_repack_block) so that a count touches ONE 64-bit word instead of four:
+//   words 0-3  low 32 bits of the four cumulative counts (symbols before the block)
+//   word  4    bits 32-39 of the four counts, one byte per symbol (2^40 symbols: any genome BWA can index)
+//   words 5-7  counts of the four symbols inside the block before symbol 32, 64 and 96, one byte per symbol
+//   words 8-15 the 128 symbols as before
+// A query for the first n symbols of the block takes the checkpoint of quarter (n-1)/32 and popcounts the quarter's word.
+struct alignas(16) Q16 { uint32_t x, y, z, w; };
+struct OccHead { Q16 lo, hx; }; // words 0-3, words 4-7: two 16-byte loads
 
-ARX_DEVI OccBlock load_block(const uint32_t *blk)
+ARX_HDI void occ_repack_block(uint32_t *blk) // in place, from BWA's layout; host side of the index upload
 {
-	OccBlock b;
-	struct alignas(16) Q16 { uint32_t x, y, z, w; };
-	const Q16 *p = (const Q16 *)blk; // 64-byte aligned: four 16-byte loads (global_load_dwordx4)
-	const Q16 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-	b.cum[0] = (uint64_t)a0.y << 32 | a0.x; b.cum[1] = (uint64_t)a0.w << 32 | a0.z;
-	b.cum[2] = (uint64_t)a1.y << 32 | a1.x; b.cum[3] = (uint64_t)a1.w << 32 | a1.z;
-	b.w[0] = (uint64_t)a2.x << 32 | a2.y; b.w[1] = (uint64_t)a2.z << 32 | a2.w;
-	b.w[2] = (uint64_t)a3.x << 32 | a3.y; b.w[3] = (uint64_t)a3.z << 32 | a3.w;
-	return b;
+	uint64_t cum[4];
+	for (int c = 0; c < 4; ++c) cum[c] = (uint64_t)blk[2 * c] | (uint64_t)blk[2 * c + 1] << 32; // little-endian u64
+	uint32_t ck[3] = {0, 0, 0}, run[4] = {0, 0, 0, 0};
+	for (int wd = 0; wd < 6; ++wd) {
+		const uint32_t x = blk[8 + wd];
+		for (int t = 0; t < 16; ++t) ++run[(x >> (30 - 2 * t)) & 3];
+		if (wd & 1) ck[wd >> 1] = run[0] | run[1] << 8 | run[2] << 16 | run[3] << 24;
+	}
+	uint32_t hi = 0;
+	for (int c = 0; c < 4; ++c) { blk[c] = (uint32_t)cum[c]; hi |= (uint32_t)((cum[c] >> 32) & 0xff) << (8 * c); }
+	blk[4] = hi; blk[5] = ck[0]; blk[6] = ck[1]; blk[7] = ck[2];
 }
 
-// counts of the four symbols among the first n (1..128) symbols of the block
-ARX_DEVI void block_count4(const OccBlock &b, int n, uint32_t cnt[4])
+ARX_DEVI OccHead load_head(const uint32_t *blk)
 {
-	uint32_t c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		int nj = n - 32 * j;                       // symbols of this 64-bit word that count
-		nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj);
-		const uint64_t keep = nj == 0 ? 0 : ~0ull << (64 - 2 * nj);
-		const uint64_t w = b.w[j];
-		const uint64_t lo = w & 0x5555555555555555ull & keep, hi = (w >> 1) & 0x5555555555555555ull & keep;
-		const uint32_t p3 = (uint32_t)__builtin_popcountll(hi & lo);
-		c3 += p3;
-		c2 += (uint32_t)__builtin_popcountll(hi) - p3;
-		c1 += (uint32_t)__builtin_popcountll(lo) - p3;
-	}
-	cnt[1] = c1; cnt[2] = c2; cnt[3] = c3; cnt[0] = (uint32_t)n - c1 - c2 - c3;
+	const Q16 *p = (const Q16 *)blk; // 64-byte aligned
+	OccHead h; h.lo = p[0]; h.hx = p[1];
+	return h;
 }
-
-ARX_DEVI uint32_t block_count1(const OccBlock &b, int n, int c)
+ARX_DEVI uint64_t load_quarter(const uint32_t *blk, int q) // symbols 32q .. 32q+31, symbol i of the quarter at bits 63-2i..62-2i
 {
-	uint32_t r = 0;
-	const uint64_t flip_lo = (c & 1) ? 0 : ~0ull, flip_hi = (c & 2) ? 0 : ~0ull;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		int nj = n - 32 * j;
-		nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj);
-		const uint64_t keep = nj == 0 ? 0 : ~0ull << (64 - 2 * nj);
-		const uint64_t w = b.w[j];
-		r += (uint32_t)__builtin_popcountll((w ^ flip_lo) & ((w >> 1) ^ flip_hi) & 0x5555555555555555ull & keep);
-	}
-	return r;
+	struct alignas(8) D8 { uint32_t a, b; };
+	const D8 d = *(const D8 *)(blk + 8 + 2 * q);
+	return (uint64_t)d.a << 32 | d.b;
+}
+ARX_DEVI uint64_t head_cum(const OccHead &h, int c) // compile-time c in the callers' unrolled loops
+{
+	const uint32_t lo = c == 0 ? h.lo.x : c == 1 ? h.lo.y : c == 2 ? h.lo.z : h.lo.w;
+	return (uint64_t)lo | (uint64_t)((h.hx.x >> (8 * c)) & 0xff) << 32;
+}
+ARX_DEVI uint32_t head_ck(const OccHead &h, int q) { return q == 0 ? 0u : q == 1 ? h.hx.y : q == 2 ? h.hx.z : h.hx.w; }
+
+// counts of the four symbols among the first n (1..128) symbols of the block, added to the cumulative counts
+ARX_DEVI void block_occ4(const uint32_t *blk, const OccHead &h, int n, uint64_t cnt[4])
+{
+	const int q = (n - 1) >> 5, nj = n - 32 * q; // nj in 1..32
+	const uint64_t w = load_quarter(blk, q);
+	const uint64_t keep = ~0ull << (64 - 2 * nj);
+	const uint64_t lo = w & 0x5555555555555555ull & keep, hi = (w >> 1) & 0x5555555555555555ull & keep;
+	const uint32_t p3 = (uint32_t)__builtin_popcountll(hi & lo);
+	const uint32_t c2 = (uint32_t)__builtin_popcountll(hi) - p3, c1 = (uint32_t)__builtin_popcountll(lo) - p3;
+	const uint32_t c0 = (uint32_t)nj - c1 - c2 - p3;
+	const uint32_t ck = head_ck(h, q);
+	cnt[0] = head_cum(h, 0) + (ck & 0xff) + c0;
+	cnt[1] = head_cum(h, 1) + ((ck >> 8) & 0xff) + c1;
+	cnt[2] = head_cum(h, 2) + ((ck >> 16) & 0xff) + c2;
+	cnt[3] = head_cum(h, 3) + (ck >> 24) + p3;
 }
 
 // bwt_occ4 (bwt.c:169-187): counts in B[0..k] of the $-removed BWT.  Touches exactly one 64-byte block.
@@ -63,39 +73,36 @@ ARX_DEVI void occ4(const IndexView &ix, uint64_t k, uint64_t cnt[4])
 {
 	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
 	k -= (k >= ix.primary);
-	const OccBlock b = load_block(ix.bwt + ((k >> 7) << 4));
-	uint32_t c4[4];
-	block_count4(b, (int)(k & 127) + 1, c4);
-	cnt[0] = b.cum[0] + c4[0]; cnt[1] = b.cum[1] + c4[1]; cnt[2] = b.cum[2] + c4[2]; cnt[3] = b.cum[3] + c4[3];
+	const uint32_t *blk = ix.bwt + ((k >> 7) << 4);
+	block_occ4(blk, load_head(blk), (int)(k & 127) + 1, cnt);
 }
 
-// bwt_2occ4 (bwt.c:189-217): both ends of an interval; when they fall into the same 64-byte block it is fetched once
+// bwt_2occ4 (bwt.c:189-217): both ends of an interval; when they fall into the same 64-byte block its head is fetched once
 ARX_DEVI void occ4_pair(const IndexView &ix, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
 {
 	if (k == (uint64_t)-1 || l == (uint64_t)-1) { occ4(ix, k, ck); occ4(ix, l, cl); return; }
 	k -= (k >= ix.primary); l -= (l >= ix.primary);
-	const OccBlock b = load_block(ix.bwt + ((k >> 7) << 4));
-	uint32_t c4[4];
-	block_count4(b, (int)(k & 127) + 1, c4);
-	ck[0] = b.cum[0] + c4[0]; ck[1] = b.cum[1] + c4[1]; ck[2] = b.cum[2] + c4[2]; ck[3] = b.cum[3] + c4[3];
-	if ((l >> 7) == (k >> 7)) {
-		block_count4(b, (int)(l & 127) + 1, c4);
-		cl[0] = b.cum[0] + c4[0]; cl[1] = b.cum[1] + c4[1]; cl[2] = b.cum[2] + c4[2]; cl[3] = b.cum[3] + c4[3];
-	} else {
-		const OccBlock b2 = load_block(ix.bwt + ((l >> 7) << 4));
-		block_count4(b2, (int)(l & 127) + 1, c4);
-		cl[0] = b2.cum[0] + c4[0]; cl[1] = b2.cum[1] + c4[1]; cl[2] = b2.cum[2] + c4[2]; cl[3] = b2.cum[3] + c4[3];
-	}
+	const uint32_t *bk = ix.bwt + ((k >> 7) << 4), *bl = ix.bwt + ((l >> 7) << 4);
+	const OccHead hk = load_head(bk);
+	OccHead hl = hk;
+	if (bl != bk) hl = load_head(bl);
+	block_occ4(bk, hk, (int)(k & 127) + 1, ck);
+	block_occ4(bl, hl, (int)(l & 127) + 1, cl);
 }
 
-// bwt_occ (bwt.c:107-130) for one symbol
-ARX_DEVI uint64_t occ1(const IndexView &ix, uint64_t k, int c)
+// symbol at position pos (0..127) of the block and its count among the block's first pos+1 symbols plus the cumulative count
+ARX_DEVI uint64_t block_occ1_at(const uint32_t *blk, const OccHead &h, int pos, int *sym)
 {
-	if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
-	if (k == (uint64_t)-1) return 0;
-	k -= (k >= ix.primary);
-	const OccBlock b = load_block(ix.bwt + ((k >> 7) << 4));
-	return b.cum[c] + block_count1(b, (int)(k & 127) + 1, c);
+	const int q = pos >> 5, o = pos & 31;
+	const uint64_t w = load_quarter(blk, q);
+	const int c = (int)(w >> (62 - 2 * o)) & 3;
+	const uint64_t keep = ~0ull << (62 - 2 * o);
+	const uint64_t flip_lo = (c & 1) ? 0 : ~0ull, flip_hi = (c & 2) ? 0 : ~0ull;
+	const uint32_t r = (uint32_t)__builtin_popcountll((w ^ flip_lo) & ((w >> 1) ^ flip_hi) & 0x5555555555555555ull & keep);
+	const uint32_t ck = head_ck(h, q);
+	const uint32_t lo = c == 0 ? h.lo.x : c == 1 ? h.lo.y : c == 2 ? h.lo.z : h.lo.w;
+	*sym = c;
+	return ((uint64_t)lo | (uint64_t)((h.hx.x >> (8 * c)) & 0xff) << 32) + ((ck >> (8 * c)) & 0xff) + r;
 }
 
 // bwt_extend (bwt.c:262-274), returning only the child for symbol c -- the SMEM search never looks at the other three.
@@ -133,11 +140,11 @@ ARX_DEVI uint64_t lf_step(const IndexView &ix, uint64_t k)
 {
 	if (k == ix.primary) return 0;
 	const uint64_t x = k - (k > ix.primary);           // row of the $-removed string holding B[k]
-	const OccBlock b = load_block(ix.bwt + ((x >> 7) << 4));
-	const int pos = (int)(x & 127);
-	const int c = (int)(b.w[pos >> 5] >> (62 - 2 * (pos & 31))) & 3;
+	const uint32_t *blk = ix.bwt + ((x >> 7) << 4);
+	int c;
 	// occ(k, c) counts B[0..x'] with x' = k - (k >= primary); for k != primary that is the same row x (k > primary <=> k >= primary)
-	return ix.L2[c] + b.cum[c] + block_count1(b, pos + 1, c);
+	const uint64_t occ = block_occ1_at(blk, load_head(blk), (int)(x & 127), &c);
+	return (c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3]) + occ;
 }
 
 // bwt_sa (bwt.c:86-96): LF steps until a sampled row
@@ -172,13 +179,15 @@ template <class Q> struct SeedLane {
 	int n, old_n, k2;               // output count; pass-2 bookkeeping
 	int x, min_intv, ret;           // current smem1 call
 	int i, j, c, n_prev, n_curr, nm, sx;
+	uint64_t curr_last_s;           // curr[n_curr - 1].s and the start of mem[nm - 1], kept in registers: both are looked at after every
+	int mem_last_start;             // backward extension and would otherwise be dependent loads from the lists in HBM
 	Biv ik;
 
 	ARX_DEVI void start(const SmemScratch &sc, int len_, const Q &q_, Biv *out_, int cap_)
 	{
 		prev = sc.v0; curr = sc.v1; mem = sc.mem; out = out_; q = q_; len = len_; cap = cap_; overflow = 0;
 		state = ST_P1_NEXT; pass = 1; n = old_n = k2 = 0; x = 0; min_intv = 1; ret = 0;
-		i = j = c = n_prev = n_curr = nm = sx = 0; ik = Biv();
+		i = j = c = n_prev = n_curr = nm = sx = 0; ik = Biv(); curr_last_s = 0; mem_last_start = 0;
 	}
 	ARX_DEVI bool done() const { return state == ST_DONE; }
 
@@ -258,7 +267,7 @@ template <class Q> struct SeedLane {
 			c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
 			n_curr = 0; j = 0;
 			if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
-				if (n_prev > 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
+				if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
 				state = ST_SMEM_DONE;
 				break;
 			}
@@ -285,10 +294,10 @@ template <class Q> struct SeedLane {
 			ik = ok; ik.info = i + 1; ++i;
 		} else if (state == ST_BWD_J) {
 			if (ok.s < (uint64_t)min_intv) {
-				if (n_curr == 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; }
-			} else if (n_curr == 0 || ok.s != curr[n_curr - 1].s) {
+				if (n_curr == 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
+			} else if (n_curr == 0 || ok.s != curr_last_s) {
 				Biv t = ok; t.info = req.info;
-				curr[n_curr++] = t;
+				curr[n_curr++] = t; curr_last_s = ok.s;
 			}
 			++j;
 		} else { // ST_STRAT
