@@ -83,3 +83,51 @@ def test_fresh_nasty_workload_matches_oracle_and_reference(built, seed, no_ahead
     parity.check_final(dev, oradrv.Oracle(prefix).batch(rs.seqs, rs.lens, n_threads=8))
     assert len(dev["regs"]) > 5000
     ref.close()
+
+
+def _run_with_rfa(ref, rs, b0, b1):
+    """Barcodes [b0, b1) as one device batch: final regions + placed candidates."""
+    import rfadrv
+    po = rs.pair_offsets()
+    p0, p1 = int(po[b0]), int(po[b1])
+    b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1]).run()
+    out = b.fetch()
+    flags = [rfadrv.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(b0, b1)]
+    cands = b.rfa(po[b0:b1 + 1] - po[b0], flags)
+    b.free()
+    return out, cands
+
+
+def test_results_do_not_depend_on_batch_shape_or_schedule(built):
+    """Size-independent property at bench scale (one chr20-size barcode set is 1,000 x 1,000 pairs; here 24 x 1,000 on an 8 Mb
+    genome): a barcode's regions, CIGARs, placements and MAPQs are the same whether it is processed in one batch of 24 barcodes,
+    in two batches of 12, or a second time -- lanes take reads in whatever order the hardware schedules them (persistent-lane
+    kernels, atomically claimed work lists), none of which may show in the output."""
+    from arachne_amd import synth
+    g = synth.make_genome(77, [6_000_000, 2_000_000])
+    rs = synth.make_reads(78, g, 24, 1000)
+    tmp = tempfile.mkdtemp(prefix="arx_gpu_shape_")
+    prefix = os.path.join(tmp, "g.fa")
+    g.write_fasta(prefix)
+    api.index_build(prefix, prefix)
+    ref = api.load_reference(prefix, 0)
+    whole, wc = _run_with_rfa(ref, rs, 0, 24)
+    again, ac = _run_with_rfa(ref, rs, 0, 24)
+    for k in ("reg_off", "regs", "alns", "cigars"):
+        assert np.array_equal(whole[k], again[k]), k
+    assert np.array_equal(wc["cands"], ac["cands"])
+    left, lc = _run_with_rfa(ref, rs, 0, 12)
+    right, rc = _run_with_rfa(ref, rs, 12, 24)
+    n_left = len(left["reg_off"]) - 1
+    assert np.array_equal(whole["reg_off"][:n_left + 1], left["reg_off"])
+    assert np.array_equal(whole["reg_off"][n_left:] - whole["reg_off"][n_left], right["reg_off"])
+    cut = int(left["reg_off"][-1])
+    assert np.array_equal(whole["regs"][:cut], left["regs"]) and np.array_equal(whole["regs"][cut:], right["regs"])
+    names = [n for n in wc["cands"].dtype.names if n not in ("reg", "read")]     # indices are batch-relative
+    nc = len(lc["cands"])
+    for n in names:
+        assert np.array_equal(wc["cands"][n][:nc], lc["cands"][n]), n
+        assert np.array_equal(wc["cands"][n][nc:], rc["cands"][n]), n
+    act = wc["cands"][wc["cands"]["active"] == 1]
+    assert len(act) == 2 * rs.n_pairs                                             # one placement per read
+    ref.close()
