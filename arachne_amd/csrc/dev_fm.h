@@ -158,8 +158,8 @@ ARX_DEVI uint64_t sa_lookup(const IndexView &ix, uint64_t k)
 // Scratch for the SMEM searches of one read: two interval lists of up to len+1 entries each plus the per-call result list.
 struct SmemScratch { Biv *v0, *v1, *mem; };
 
-// mem_collect_intv (bwamem.c:114-162): SMEM pass (bwt_smem1a, bwt.c:289-351, max_intv = 0), re-seeding pass from the
-// middle of long rare SMEMs, LAST-like pass (bwt_seed_strategy1, bwt.c:358-379), then sort by info.
+// mem_collect_intv (bwamem.c:114-162), first two passes: SMEM pass (bwt_smem1a, bwt.c:289-351, max_intv = 0) and the
+// re-seeding pass from the middle of long rare SMEMs.  (Third pass: StratLane below; the final sort: seed_merge.)
 //
 // The reference nests these loops around bwt_extend(); here they are flattened into a resumable lane program: advance()
 // runs the bookkeeping of one read until it needs its next extension (the only expensive step: two random 64-byte Occ
@@ -171,7 +171,7 @@ struct QBytes { const uint8_t *p; ARX_DEVI int at(int i) const { return p[i]; } 
 struct QNibbles { const uint8_t *p; ARX_DEVI int at(int i) const { return (p[i >> 1] >> ((i & 1) << 2)) & 15; } }; // two per byte (LDS staging)
 
 template <class Q> struct SeedLane {
-	enum { ST_P1_NEXT, ST_P2_NEXT, ST_P3_NEXT, ST_FWD, ST_FWD_DONE, ST_BWD_ROW, ST_BWD_J, ST_SMEM_DONE, ST_STRAT, ST_DONE };
+	enum { ST_P1_NEXT, ST_P2_NEXT, ST_FWD, ST_FWD_DONE, ST_BWD_ROW, ST_BWD_J, ST_SMEM_DONE, ST_DONE };
 	Biv *prev, *curr, *mem, *out;
 	Q q;
 	int len, cap, overflow;
@@ -213,11 +213,6 @@ template <class Q> struct SeedLane {
 				}
 				*req = prev[j]; *rb = 1; *rc = c;
 				return true;
-			case ST_STRAT: // shortest forward match of > min_seed_len bases occurring < max_mem_intv times
-				if (i >= len) { x = len; state = ST_P3_NEXT; break; }
-				if (q.at(i) > 3) { x = i + 1; state = ST_P3_NEXT; break; }
-				*req = ik; *rb = 0; *rc = 3 - q.at(i);
-				return true;
 			default:
 				if (!slow_ok) return false;
 				slow_step(ix);
@@ -226,7 +221,6 @@ template <class Q> struct SeedLane {
 		}
 		return false;
 	}
-	ARX_DEVI bool parked() const { return state != ST_DONE && state != ST_FWD && state != ST_BWD_J && state != ST_STRAT; }
 	ARX_DEV void slow_step(const IndexView &ix)
 	{
 		switch (state) {
@@ -245,16 +239,11 @@ template <class Q> struct SeedLane {
 				found = true;
 				break;
 			}
-			if (!found) { x = 0; state = ST_P3_NEXT; break; }
+			if (!found) { state = ST_DONE; break; } // the third pass runs on its own (StratLane)
 			if (q.at(x) > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
 			ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
 			break;
 		}
-		case ST_P3_NEXT:
-			while (x < len && q.at(x) > 3) ++x;
-			if (x >= len) { finish(); break; }
-			ik = set_intv(ix, q.at(x)); sx = x; i = x + 1; state = ST_STRAT;
-			break;
 		case ST_FWD_DONE: {
 			for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
 			ret = (int)curr[0].info;
@@ -292,7 +281,7 @@ template <class Q> struct SeedLane {
 				if (ok.s < (uint64_t)min_intv) { state = ST_FWD_DONE; return; }
 			}
 			ik = ok; ik.info = i + 1; ++i;
-		} else if (state == ST_BWD_J) {
+		} else { // ST_BWD_J
 			if (ok.s < (uint64_t)min_intv) {
 				if (n_curr == 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
 			} else if (n_curr == 0 || ok.s != curr_last_s) {
@@ -300,42 +289,55 @@ template <class Q> struct SeedLane {
 				curr[n_curr++] = t; curr_last_s = ok.s;
 			}
 			++j;
-		} else { // ST_STRAT
-			if (ok.s < (uint64_t)OPT_MAX_MEM_INTV && i - sx >= OPT_MIN_SEED_LEN) {
-				if (ok.s > 0) { Biv t = ok; t.info = (uint64_t)sx << 32 | (uint32_t)(i + 1); if (n < cap) out[n++] = t; else overflow = 1; }
-				x = i + 1; state = ST_P3_NEXT;
-			} else { ik = ok; ++i; }
 		}
-	}
-	ARX_DEVI void finish() // insertion sort by info
-	{
-		for (int a = 1; a < n; ++a) {
-			Biv t = out[a];
-			int b = a;
-			while (b > 0 && out[b - 1].info > t.info) { out[b] = out[b - 1]; --b; }
-			out[b] = t;
-		}
-		state = ST_DONE;
-	}
-	// seed occurrences the intervals expand to (bwamem.c:273-283: at most max_occ rows per interval)
-	ARX_DEVI int occurrences() const
-	{
-		int occ = 0;
-		for (int a = 0; a < n; ++a) occ += out[a].s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)out[a].s;
-		return occ;
 	}
 };
 
-// one read from start to end.  Returns the number of intervals written to out (capacity cap); *overflow is set when more were found.
-ARX_DEV int collect_intv(const IndexView &ix, int len, const uint8_t *q, const SmemScratch &sc, Biv *out, int cap, int *overflow)
+// Third pass of mem_collect_intv: bwt_seed_strategy1 (bwt.c:358-379) from every position a match can start at -- the
+// shortest forward match longer than min_seed_len that occurs fewer than max_mem_intv times.  It does not look at the
+// results of the first two passes, so it is its own lane program (forward extensions only, next to no bookkeeping) and
+// runs as its own kernel; seed_merge() joins the two interval lists.
+constexpr int CAP_STRAT = 16; // a hit consumes at least min_seed_len + 1 bases: <= MAX_READ_LEN / 20 hits per read
+template <class Q> struct StratLane {
+	Q q; Biv *out; int len, n, x, i, sx; bool fresh, finished; Biv ik;
+	ARX_DEVI void start(int len_, const Q &q_, Biv *out_) { q = q_; out = out_; len = len_; n = 0; x = 0; i = 0; sx = 0; fresh = true; finished = false; ik = Biv(); }
+	ARX_DEVI bool done() const { return finished; }
+	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rc)
+	{
+		for (;;) {
+			if (fresh) {
+				while (x < len && q.at(x) > 3) ++x;
+				if (x >= len) { finished = true; return false; }
+				ik = set_intv(ix, q.at(x)); sx = x; i = x + 1; fresh = false;
+			}
+			if (i >= len) { finished = true; return false; } // bwt_seed_strategy1 returns len: the pass ends
+			if (q.at(i) > 3) { x = i + 1; fresh = true; continue; }
+			*req = ik; *rc = 3 - q.at(i);
+			return true;
+		}
+	}
+	ARX_DEVI void consume(const Biv &ok)
+	{
+		if (ok.s < (uint64_t)OPT_MAX_MEM_INTV && i - sx >= OPT_MIN_SEED_LEN) {
+			if (ok.s > 0 && n < CAP_STRAT) { Biv t = ok; t.info = (uint64_t)sx << 32 | (uint32_t)(i + 1); out[n++] = t; }
+			x = i + 1; fresh = true;
+		} else { ik = ok; ++i; }
+	}
+};
+
+// Both interval lists of a read -> out (capacity cap), sorted by info (bwamem.c:160).  Entries with equal info describe the
+// same query substring and hence the same bi-interval, so any sort reproduces ks_introsort's result.  Returns the length.
+ARX_DEV int seed_merge(Biv *out, int n12, const Biv *strat, int n3, int cap, int *overflow)
 {
-	SeedLane<QBytes> ln;
-	ln.start(sc, len, QBytes{q}, out, cap);
-	Biv req = Biv();
-	int rb = 0, rc = 0;
-	while (ln.advance(ix, &req, &rb, &rc)) ln.consume(req, extend1(ix, req, rb, rc));
-	if (ln.overflow) *overflow = 1;
-	return ln.n;
+	int n = n12;
+	for (int a = 0; a < n3; ++a) { if (n < cap) out[n++] = strat[a]; else *overflow = 1; }
+	for (int a = 1; a < n; ++a) { // insertion sort by info
+		Biv t = out[a];
+		int b = a;
+		while (b > 0 && out[b - 1].info > t.info) { out[b] = out[b - 1]; --b; }
+		out[b] = t;
+	}
+	return n;
 }
 
 } // namespace arx

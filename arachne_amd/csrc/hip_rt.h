@@ -113,6 +113,7 @@ struct HipRT {
 	int bpc = getenv("ARX_BPC") ? atoi(getenv("ARX_BPC")) : 16;           // resident 64-lane blocks per CU of the thread-per-item kernels (sizes their per-slot scratch)
 	int coop_bpc = getenv("ARX_COOP_BPC") ? atoi(getenv("ARX_COOP_BPC")) : 64; // grid cap of the 16-lane DP kernels (no per-slot scratch; grid-stride)
 	int ext_merge_below = getenv("ARX_EXT_MERGE") ? atoi(getenv("ARX_EXT_MERGE")) : 30000; // rounds with fewer extensions run all length classes in one launch
+	int strat_bpc = getenv("ARX_STRAT_BPC") ? atoi(getenv("ARX_STRAT_BPC")) : 16; // resident blocks per CU of the third seeding pass
 	int max_blocks() const { return n_cu * bpc; }
 	int coop_blocks(int n) const { int b = (n + 3) / 4, cap = n_cu * coop_bpc; return b < cap ? b : cap; }
 	int max_slots() const { return max_blocks() * 64; }
@@ -211,11 +212,23 @@ struct HipRT {
 		if (sw_simple) { launch(nm, n, f); return; }
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
-		SeedArgs A{f.ix, f.bases, f.base_off, f.lens, f.intv, f.n_intv, f.n_occ, f.scratch, f.list_cap, f.err};
+		SeedArgs A{f.ix, f.bases, f.base_off, f.lens, f.intv, f.n_intv, f.scratch, f.list_cap, f.err};
 		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
 		static const int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 16; // lanes that queue up before the slow bookkeeping runs
 		static const int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64;  // reads a wavefront reserves per atomic
 		hipLaunchKernelGGL(k_seed_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_batch, seed_chunk);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	template <class F> void run_seed_strat(const char *nm, int n, const F &f, int32_t *counter)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch(nm, n, f); return; }
+		memset0(counter, 4);
+		Scope sc(*this, nm, n);
+		StratArgs A{f.ix, f.bases, f.base_off, f.lens, f.strat, f.n_strat};
+		static const int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64;
+		int blocks = (n + 63) / 64; if (blocks > n_cu * strat_bpc) blocks = n_cu * strat_bpc;
+		hipLaunchKernelGGL(k_strat_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_chunk);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// locate: persistent lanes with wave-level work distribution (hip_fm_coop.h); 32 waves per CU to cover the miss latency

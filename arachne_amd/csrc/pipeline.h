@@ -22,23 +22,57 @@
 namespace arx {
 
 // ---------------------------------------------------------------- kernel functors (item = work unit, slot = scratch slot)
-struct KSeed {
+struct KSeed { // passes 1 and 2 of mem_collect_intv for one read (the HIP runtime drives SeedLane with persistent lanes instead, hip_fm_coop.h)
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens;
-	Biv *intv; int32_t *n_intv, *n_occ; Biv *scratch; int list_cap; uint32_t *err;
+	Biv *intv; int32_t *n_intv; Biv *scratch; int list_cap; uint32_t *err;
 	ARX_DEV void operator()(int r, int slot) const
 	{
-		int len = lens[r], ovf = 0, n = 0, occ = 0;
+		int len = lens[r], n = 0;
 		if (len > MAX_READ_LEN) { atomic_or_err(err, ERR_READ_TOO_LONG); len = 0; }
 		if (len >= OPT_MIN_SEED_LEN) {
 			SmemScratch sc; sc.v0 = scratch + (size_t)slot * 3 * list_cap; sc.v1 = sc.v0 + list_cap; sc.mem = sc.v1 + list_cap;
-			Biv *out = intv + (size_t)r * CAP_INTV;
-			n = collect_intv(ix, len, bases + base_off[r], sc, out, CAP_INTV, &ovf);
-			for (int i = 0; i < n; ++i) occ += out[i].s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)out[i].s;
+			SeedLane<QBytes> ln;
+			ln.start(sc, len, QBytes{bases + base_off[r]}, intv + (size_t)r * CAP_INTV, CAP_INTV);
+			Biv req = Biv();
+			int rb = 0, rc = 0;
+			while (ln.advance(ix, &req, &rb, &rc)) ln.consume(req, extend1(ix, req, rb, rc));
+			if (ln.overflow) atomic_or_err(err, ERR_INTV_OVERFLOW);
+			n = ln.n;
 		}
-		if (ovf) atomic_or_err(err, ERR_INTV_OVERFLOW);
-		n_intv[r] = n; n_occ[r] = occ;
+		n_intv[r] = n;
 	}
 	static ARX_DEVI void atomic_or_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); }
+};
+
+struct KSeedStrat { // pass 3 for one read
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat;
+	ARX_DEV void operator()(int r, int) const
+	{
+		const int len = lens[r];
+		int n = 0;
+		if (len >= OPT_MIN_SEED_LEN && len <= MAX_READ_LEN) {
+			StratLane<QBytes> ln;
+			ln.start(len, QBytes{bases + base_off[r]}, strat + (size_t)r * CAP_STRAT);
+			Biv req = Biv();
+			int rc = 0;
+			while (ln.advance(ix, &req, &rc)) ln.consume(extend1(ix, req, 0, rc));
+			n = ln.n;
+		}
+		n_strat[r] = n;
+	}
+};
+
+struct KSeedMerge { // both interval lists of a read, sorted; the number of seed occurrences they expand to (bwamem.c:273-283: at most max_occ rows per interval)
+	Biv *intv; int32_t *n_intv; const Biv *strat; const int32_t *n_strat; int32_t *n_occ; uint32_t *err;
+	ARX_DEV void operator()(int r, int) const
+	{
+		Biv *out = intv + (size_t)r * CAP_INTV;
+		int ovf = 0, occ = 0;
+		const int n = seed_merge(out, n_intv[r], strat + (size_t)r * CAP_STRAT, n_strat[r], CAP_INTV, &ovf);
+		for (int i = 0; i < n; ++i) occ += out[i].s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)out[i].s;
+		if (ovf) KSeed::atomic_or_err(err, ERR_INTV_OVERFLOW);
+		n_intv[r] = n; n_occ[r] = occ;
+	}
 };
 
 // per read: expand its intervals into seed occurrences (bwamem.c:273-283): at most max_occ rows per interval, evenly
@@ -327,8 +361,14 @@ public:
 		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);
 		w.smem_scr = rt.template alloc<Biv>((size_t)slots * 3 * list_cap);
 		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
-		KSeed k{ix, b.bases, b.base_off, b.lens, w.intv, w.n_intv, w.n_occ, w.smem_scr, list_cap, w.err};
+		Biv *strat = rt.template alloc<Biv>((size_t)R * CAP_STRAT);
+		int32_t *n_strat = rt.template alloc<int32_t>(R + 1);
+		KSeed k{ix, b.bases, b.base_off, b.lens, w.intv, w.n_intv, w.smem_scr, list_cap, w.err};
 		rt.run_seed("seed", R, k, w.counter);
+		KSeedStrat k3{ix, b.bases, b.base_off, b.lens, strat, n_strat};
+		rt.run_seed_strat("seed_strat", R, k3, w.counter);
+		KSeedMerge km{w.intv, w.n_intv, strat, n_strat, w.n_occ, w.err};
+		rt.launch("seed_merge", R, km);
 		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R);
 		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
 		w.T = total;

@@ -514,7 +514,8 @@ static int seed_strategy1(const index_t *ix, int len, const uint8_t *q, int x, i
 	for (i = x + 1; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
-			extend(ix, &ik, ok, 0, cnt);
+			if (cnt) { const int64_t e1 = cnt->ext_same_block, e2 = cnt->ext_two_block; extend(ix, &ik, ok, 0, cnt); cnt->ext3_same_block += cnt->ext_same_block - e1; cnt->ext3_two_block += cnt->ext_two_block - e2; }
+			else extend(ix, &ik, ok, 0, cnt);
 			if (ok[c].s < (uint64_t)max_intv && i - x >= min_len) {
 				*mem = ok[c];
 				mem->info = (uint64_t)x << 32 | (i + 1);

@@ -34,6 +34,7 @@ typedef struct {
 	int64_t cells_u8;        /* ksw_u8 cell updates (qlen_padded x rows) */
 	int64_t cells_global;    /* ksw_global2 cell updates */
 	int64_t n_extend_calls, n_u8_calls, n_global_calls;
+	int64_t ext3_same_block, ext3_two_block; /* the share of E1 / E2 spent in the third seeding pass (bwt_seed_strategy1) */
 } ora_counters_t;
 
 #ifdef __cplusplus
