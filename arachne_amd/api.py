@@ -240,4 +240,5 @@ class Reference:
 
 
 def load_reference(prefix: str, device: int = 0) -> Reference:
-    return Reference(prefix, device)
+    # ARX_LIB (experiments only): another build of the same HIP library, e.g. a kernel variant under comparison
+    return Reference(prefix, device, lib_path=os.environ.get("ARX_LIB", LIB_PATH))

@@ -181,22 +181,19 @@ template <class Q> struct SeedLane {
 	int i, j, c, n_prev, n_curr, nm, sx;
 	uint64_t curr_last_s;           // curr[n_curr - 1].s and the start of mem[nm - 1], kept in registers: both are looked at after every
 	int mem_last_start;             // backward extension and would otherwise be dependent loads from the lists in HBM
-	Biv nxt; int nxt_j;             // prev[nxt_j], fetched ahead (-1: nothing)
-	Biv curr_first;                 // curr[0] of the row being built
-	int row_from_regs;
 	Biv ik;
 
 	ARX_DEVI void start(const SmemScratch &sc, int len_, const Q &q_, Biv *out_, int cap_)
 	{
 		prev = sc.v0; curr = sc.v1; mem = sc.mem; out = out_; q = q_; len = len_; cap = cap_; overflow = 0;
 		state = ST_P1_NEXT; pass = 1; n = old_n = k2 = 0; x = 0; min_intv = 1; ret = 0;
-		i = j = c = n_prev = n_curr = nm = sx = 0; ik = Biv(); curr_last_s = 0; mem_last_start = 0; nxt = Biv(); nxt_j = -1; curr_first = Biv(); row_from_regs = 0;
+		i = j = c = n_prev = n_curr = nm = sx = 0; ik = Biv(); curr_last_s = 0; mem_last_start = 0;
 	}
 	ARX_DEVI bool done() const { return state == ST_DONE; }
 
 	// Bookkeeping until the read needs an extension (true: *req extended by symbol *rc, backward if *rb) or is finished
-	// (false).  The states of the extension loops (forward step, backward step, next backward row) are cheap; everything
-	// between two searches (list reversal, SMEM output, picking the next start) is rare per lane but long.  With slow_ok = false the lane stops in front of such a
+	// (false).  The three states that ask for extensions are cheap; everything between two searches (list reversal, SMEM
+	// output, picking the next start) is rare per lane but long.  With slow_ok = false the lane stops in front of such a
 	// state (false, !done()): a wavefront driver lets lanes queue up there and runs them together, instead of paying for
 	// every rare path in every iteration because one of its 64 lanes is in it.
 	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rb, int *rc, bool slow_ok = true)
@@ -211,28 +208,11 @@ template <class Q> struct SeedLane {
 				if (j >= n_prev) {
 					if (n_curr == 0) { state = ST_SMEM_DONE; break; }
 					Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-					--i; state = ST_BWD_ROW; row_from_regs = 1;
+					--i; state = ST_BWD_ROW;
 					break;
 				}
-				// prev[j] was fetched while the previous extension of this row was in flight; fetch prev[j + 1] now, next to the
-				// Occ blocks of this one, so that a backward step costs one trip to HBM instead of two dependent ones
-				*req = nxt_j == j ? nxt : prev[j];
-				nxt_j = -1;
-				if (j + 1 < n_prev) { nxt = prev[j + 1]; nxt_j = j + 1; }
-				*rb = 1; *rc = c;
+				*req = prev[j]; *rb = 1; *rc = c;
 				return true;
-			case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
-				if (i < -1) { state = ST_SMEM_DONE; break; }
-				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
-				n_curr = 0; j = 0; nxt_j = -1;
-				if (row_from_regs) { nxt = curr_first; nxt_j = 0; row_from_regs = 0; } // prev[0] is the first entry the previous row pushed
-				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
-					if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
-					state = ST_SMEM_DONE;
-					break;
-				}
-				state = ST_BWD_J;
-				break;
 			default:
 				if (!slow_ok) return false;
 				slow_step(ix);
@@ -271,6 +251,17 @@ template <class Q> struct SeedLane {
 			i = x - 1; state = ST_BWD_ROW;
 			break;
 		}
+		case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
+			if (i < -1) { state = ST_SMEM_DONE; break; }
+			c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
+			n_curr = 0; j = 0;
+			if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
+				if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
+				state = ST_SMEM_DONE;
+				break;
+			}
+			state = ST_BWD_J;
+			break;
 		case ST_SMEM_DONE:
 			for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
 				const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
@@ -295,7 +286,6 @@ template <class Q> struct SeedLane {
 				if (n_curr == 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
 			} else if (n_curr == 0 || ok.s != curr_last_s) {
 				Biv t = ok; t.info = req.info;
-				if (n_curr == 0) curr_first = t; // the next row starts from this entry: keep it out of HBM's latency
 				curr[n_curr++] = t; curr_last_s = ok.s;
 			}
 			++j;

@@ -143,12 +143,7 @@ static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32
 			// everything up to the next request (a read that ends here is written out the next time round)
 			if (r >= 0 && !have_req) have_req = ln.advance(A.ix, &req, &rb, &rc, true);
 		}
-		// One kind of extension per iteration: the forward and the backward search keep different books, and a wavefront whose
-		// lanes are all in the same kind skips the other kind's code instead of walking through both.  The majority goes, the
-		// others keep their request for a later iteration.
-		const unsigned long long fwd = __ballot(have_req && rb == 0), bwd = __ballot(have_req && rb != 0);
-		const int want_rb = __builtin_popcountll(fwd) >= __builtin_popcountll(bwd) ? 0 : 1;
-		if (have_req && rb == want_rb) { ln.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
+		if (have_req) { ln.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}
 }
 
