@@ -155,143 +155,175 @@ ARX_DEVI uint64_t sa_lookup(const IndexView &ix, uint64_t k)
 	return sa + ix.sa[k / (uint64_t)ix.sa_intv];
 }
 
-// Scratch for the SMEM searches of one read: two interval lists of up to len+1 entries each plus the per-call result list.
-struct SmemScratch { Biv *v0, *v1, *mem; };
-
-// mem_collect_intv (bwamem.c:114-162), first two passes: SMEM pass (bwt_smem1a, bwt.c:289-351, max_intv = 0) and the
-// re-seeding pass from the middle of long rare SMEMs.  (Third pass: StratLane below; the final sort: seed_merge.)
+// ---- mem_collect_intv (bwamem.c:114-162), first two passes: the SMEM pass (bwt_smem1a, bwt.c:289-351, max_intv = 0) from
+// successive start positions, and the re-seeding pass from the middle of long rare SMEMs.  (Third pass: StratLane below; the
+// final sort: seed_merge.)
 //
-// The reference nests these loops around bwt_extend(); here they are flattened into a resumable lane program: advance()
-// runs the bookkeeping of one read until it needs its next extension (the only expensive step: two random 64-byte Occ
-// blocks) or is finished, consume() takes the extension's result.  A caller that drives many lanes (hip_fm_coop.h) lets
-// the 64 reads of a wavefront -- each somewhere else in its own forward/backward search -- reconverge on extend1(), and
-// gives a lane its next read as soon as the previous one is finished.  Entries with equal info describe the same query
-// substring and hence the same bi-interval, so any sort reproduces ks_introsort's result.
+// bwt_smem1a(x) is a forward extension from x that remembers the interval each time its size changes, followed by a backward
+// sweep over those intervals.  The reference nests both around bwt_extend() and runs the calls of a read one after the
+// other; here they are cut into small lane programs that do nothing but one kind of extension each, so that the loop a
+// wavefront runs is little more than extend1() (two random 64-byte Occ blocks) -- the same shape as the third pass, which
+// reaches ~85 % of the scattered-read ceiling of the memory system (profiles/):
+//   FwdLane   the forward extension from one start.  The next start of the first pass is where the forward extension ended
+//             (bwt_smem1a's return value), so a read's starts chain through FwdLanes only.
+//   BwdLane   the backward sweep of one start: an independent task once its interval list exists.
+//   seed_gather_pass1 / _pass2   collect the SMEMs of a read's tasks in call order; the first also picks the re-seeding
+//             starts (bwamem.c:131-146), each of which is again one FwdLane + one BwdLane task.
+// A task's lists live in a slice of a batch-wide interval pool: [0, n) the forward list (longest first), [n, 2n) the
+// second list of the sweep, [2n, 3n) the SMEMs it finds.
 struct QBytes { const uint8_t *p; ARX_DEVI int at(int i) const { return p[i]; } };       // base codes 0..4, one per byte
 struct QNibbles { const uint8_t *p; ARX_DEVI int at(int i) const { return (p[i >> 1] >> ((i & 1) << 2)) & 15; } }; // two per byte (LDS staging)
 
-template <class Q> struct SeedLane {
-	enum { ST_P1_NEXT, ST_P2_NEXT, ST_FWD, ST_FWD_DONE, ST_BWD_ROW, ST_BWD_J, ST_SMEM_DONE, ST_DONE };
-	Biv *prev, *curr, *mem, *out;
-	Q q;
-	int len, cap, overflow;
-	int state, pass;
-	int n, old_n, k2;               // output count; pass-2 bookkeeping
-	int x, min_intv, ret;           // current smem1 call
-	int i, j, c, n_prev, n_curr, nm, sx;
-	uint64_t curr_last_s;           // curr[n_curr - 1].s and the start of mem[nm - 1], kept in registers: both are looked at after every
-	int mem_last_start;             // backward extension and would otherwise be dependent loads from the lists in HBM
-	Biv ik;
+struct SeedTask { int32_t read, x, min_intv, off, n, nm, next, pad; }; // off/n: pool slice; nm: SMEMs found; next: the read's next task (-1: last)
 
-	ARX_DEVI void start(const SmemScratch &sc, int len_, const Q &q_, Biv *out_, int cap_)
+struct SeedPools { // batch-wide, filled through atomic cursors; an overflow raises ERR_POOL_OVERFLOW and the read yields no more tasks
+	Biv *pool; int64_t pool_cap; SeedTask *tasks; int32_t task_cap; int32_t *cursors; // cursors[0]: pool entries handed out, [1]: tasks
+	uint32_t *err;
+	ARX_DEVI int new_task(int read, int x, int min_intv, int n) const // reserves the task and 3n pool entries; -1 on overflow
 	{
-		prev = sc.v0; curr = sc.v1; mem = sc.mem; out = out_; q = q_; len = len_; cap = cap_; overflow = 0;
-		state = ST_P1_NEXT; pass = 1; n = old_n = k2 = 0; x = 0; min_intv = 1; ret = 0;
-		i = j = c = n_prev = n_curr = nm = sx = 0; ik = Biv(); curr_last_s = 0; mem_last_start = 0;
+		const int t = ARX_ATOMIC_ADD(cursors + 1, 1);
+		const int off = ARX_ATOMIC_ADD(cursors, 3 * n);
+		if (t >= task_cap || (int64_t)off + 3 * n > pool_cap) { ARX_ATOMIC_OR(err, ERR_POOL_OVERFLOW); return -1; }
+		SeedTask k; k.read = read; k.x = x; k.min_intv = min_intv; k.off = off; k.n = n; k.nm = 0; k.next = -1; k.pad = 0;
+		tasks[t] = k;
+		return t;
 	}
-	ARX_DEVI bool done() const { return state == ST_DONE; }
+};
 
-	// Bookkeeping until the read needs an extension (true: *req extended by symbol *rc, backward if *rb) or is finished
-	// (false).  The three states that ask for extensions are cheap; everything between two searches (list reversal, SMEM
-	// output, picking the next start) is rare per lane but long.  With slow_ok = false the lane stops in front of such a
-	// state (false, !done()): a wavefront driver lets lanes queue up there and runs them together, instead of paying for
-	// every rare path in every iteration because one of its 64 lanes is in it.
-	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rb, int *rc, bool slow_ok = true)
+// forward half of bwt_smem1a (bwt.c:299-321) from position x (q[x] is a base): list[] receives the interval each time its
+// size changes, shortest match first
+template <class Q> struct FwdLane {
+	Q q; Biv *list; int len, i, min_intv, n; bool finished; Biv ik;
+	ARX_DEVI void start(const IndexView &ix, int len_, const Q &q_, int x, int min_intv_, Biv *list_)
 	{
-		while (state != ST_DONE) {
-			switch (state) {
-			case ST_FWD: // forward extension at query position i; the interval is remembered each time its size changes
-				if (i >= len || q.at(i) > 3) { curr[n_curr++] = ik; state = ST_FWD_DONE; break; }
-				*req = ik; *rb = 0; *rc = 3 - q.at(i);
-				return true;
-			case ST_BWD_J:
-				if (j >= n_prev) {
-					if (n_curr == 0) { state = ST_SMEM_DONE; break; }
-					Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-					--i; state = ST_BWD_ROW;
+		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false;
+		ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1;
+	}
+	ARX_DEVI bool advance(Biv *req, int *rc)
+	{
+		if (finished) return false;
+		if (i >= len || q.at(i) > 3) { list[n++] = ik; finished = true; return false; }
+		*req = ik; *rc = 3 - q.at(i);
+		return true;
+	}
+	ARX_DEVI void consume(const Biv &ok)
+	{
+		if (ok.s != ik.s) {
+			list[n++] = ik;
+			if (ok.s < (uint64_t)min_intv) { finished = true; return; }
+		}
+		ik = ok; ik.info = i + 1; ++i;
+	}
+	ARX_DEVI int ret() const { return (int)list[n - 1].info; } // where the longest match ends: the next start of the first pass
+};
+
+// list[0..n) of a finished forward extension becomes a task: the pool slice gets it longest first (bwt.c:322)
+ARX_DEVI int seed_export(const SeedPools &P, int read, int x, int min_intv, const Biv *list, int n)
+{
+	const int t = P.new_task(read, x, min_intv, n);
+	if (t < 0) return -1;
+	Biv *dst = P.pool + P.tasks[t].off;
+	for (int k = 0; k < n; ++k) dst[k] = list[n - 1 - k];
+	return t;
+}
+
+// same for a task that exists already (re-seeding): reserve its slice now that the length is known
+ARX_DEVI void seed_export_into(const SeedPools &P, int t, const Biv *list, int n)
+{
+	const int off = ARX_ATOMIC_ADD(P.cursors, 3 * n);
+	if ((int64_t)off + 3 * n > P.pool_cap) { ARX_ATOMIC_OR(P.err, ERR_POOL_OVERFLOW); return; } // n stays 0: the task is skipped
+	Biv *dst = P.pool + off;
+	for (int k = 0; k < n; ++k) dst[k] = list[n - 1 - k];
+	P.tasks[t].off = off; P.tasks[t].n = n;
+}
+
+// backward half of bwt_smem1a (bwt.c:323-349) for one task
+template <class Q> struct BwdLane {
+	Q q; Biv *prev, *curr, *mem; int min_intv, i, j, c, n_prev, n_curr, nm, mem_last_start; bool finished, in_row;
+	uint64_t curr_last_s; // curr[n_curr - 1].s and the start of mem[nm - 1] are kept in registers: both are looked at after every extension
+	ARX_DEVI void start(const Q &q_, const SeedTask &t, Biv *pool)
+	{
+		q = q_; prev = pool + t.off; curr = prev + t.n; mem = curr + t.n; min_intv = t.min_intv;
+		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
+	}
+	ARX_DEVI bool advance(Biv *req, int *rc)
+	{
+		while (!finished) {
+			if (!in_row) { // backward extension by query position i (-1 = before the read)
+				if (i < -1) { finished = true; break; }
+				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
+				n_curr = 0; j = 0;
+				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
+					if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
+					finished = true;
 					break;
 				}
-				*req = prev[j]; *rb = 1; *rc = c;
-				return true;
-			default:
-				if (!slow_ok) return false;
-				slow_step(ix);
-				break;
+				in_row = true;
 			}
+			if (j >= n_prev) {
+				if (n_curr == 0) { finished = true; break; }
+				Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+				--i; in_row = false;
+				continue;
+			}
+			*req = prev[j]; *rc = c;
+			return true;
 		}
 		return false;
 	}
-	ARX_DEV void slow_step(const IndexView &ix)
-	{
-		switch (state) {
-		case ST_P1_NEXT:
-			while (x < len && q.at(x) > 3) ++x;
-			if (x >= len) { old_n = n; k2 = 0; pass = 2; state = ST_P2_NEXT; break; }
-			min_intv = 1; ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
-			break;
-		case ST_P2_NEXT: {
-			bool found = false;
-			while (k2 < old_n) { // re-seed from the middle of SMEMs that are long and occur rarely
-				const Biv p = out[k2];
-				const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
-				if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) { ++k2; continue; }
-				x = (start + end) >> 1; min_intv = (int)p.s + 1;
-				found = true;
-				break;
-			}
-			if (!found) { state = ST_DONE; break; } // the third pass runs on its own (StratLane)
-			if (q.at(x) > 3) { nm = 0; ret = x + 1; state = ST_SMEM_DONE; break; } // bwt_smem1a returns at once on an ambiguous base
-			ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1; n_curr = 0; nm = 0; state = ST_FWD;
-			break;
-		}
-		case ST_FWD_DONE: {
-			for (int t = 0; t < n_curr >> 1; ++t) { Biv tmp = curr[n_curr - 1 - t]; curr[n_curr - 1 - t] = curr[t]; curr[t] = tmp; } // longest first
-			ret = (int)curr[0].info;
-			Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
-			i = x - 1; state = ST_BWD_ROW;
-			break;
-		}
-		case ST_BWD_ROW: // backward extension by query position i (-1 = before the read)
-			if (i < -1) { state = ST_SMEM_DONE; break; }
-			c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
-			n_curr = 0; j = 0;
-			if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
-				if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
-				state = ST_SMEM_DONE;
-				break;
-			}
-			state = ST_BWD_J;
-			break;
-		case ST_SMEM_DONE:
-			for (int t = nm - 1; t >= 0; --t) { // mem holds the SMEMs by decreasing start; emit them by increasing start
-				const int slen = (int)((uint32_t)mem[t].info - (uint32_t)(mem[t].info >> 32));
-				if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[t]; else overflow = 1; }
-			}
-			if (pass == 1) { x = ret; state = ST_P1_NEXT; } else { ++k2; state = ST_P2_NEXT; }
-			break;
-		default: break;
-		}
-	}
-	// result of the extension advance() asked for
 	ARX_DEVI void consume(const Biv &req, const Biv &ok)
 	{
-		if (state == ST_FWD) {
-			if (ok.s != ik.s) {
-				curr[n_curr++] = ik;
-				if (ok.s < (uint64_t)min_intv) { state = ST_FWD_DONE; return; }
-			}
-			ik = ok; ik.info = i + 1; ++i;
-		} else { // ST_BWD_J
-			if (ok.s < (uint64_t)min_intv) {
-				if (n_curr == 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
-			} else if (n_curr == 0 || ok.s != curr_last_s) {
-				Biv t = ok; t.info = req.info;
-				curr[n_curr++] = t; curr_last_s = ok.s;
-			}
-			++j;
+		if (ok.s < (uint64_t)min_intv) {
+			if (n_curr == 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
+		} else if (n_curr == 0 || ok.s != curr_last_s) {
+			Biv t = ok; t.info = req.info;
+			curr[n_curr++] = t; curr_last_s = ok.s;
 		}
+		++j;
 	}
 };
+
+// SMEMs of task t -> out[n...] (bwt.c:350, bwamem.c:125-129): the sweep found them by decreasing start, they are emitted by
+// increasing start, those shorter than min_seed_len dropped
+ARX_DEVI int seed_emit(const SeedTask &t, const Biv *pool, Biv *out, int n, int cap, int *overflow)
+{
+	const Biv *mem = pool + t.off + 2 * t.n;
+	for (int k = t.nm - 1; k >= 0; --k) {
+		const int slen = (int)((uint32_t)mem[k].info - (uint32_t)(mem[k].info >> 32));
+		if (slen >= OPT_MIN_SEED_LEN) { if (n < cap) out[n++] = mem[k]; else *overflow = 1; }
+	}
+	return n;
+}
+
+// After the first pass: the read's SMEMs in call order, then one re-seeding task per SMEM that is long and occurs rarely
+// (bwamem.c:131-146): start in its middle, min_intv = its occurrences + 1.  The tasks are chained in that order through
+// `next`; *first2 receives the head.  Their forward extensions have not run yet (n = 0 marks that).  Returns the SMEM count.
+ARX_DEV int seed_gather_pass1(const SeedPools &P, int read, int first_task, const uint8_t *q, Biv *out, int cap, int *overflow, int32_t *first2)
+{
+	int n = 0;
+	for (int t = first_task; t >= 0; t = P.tasks[t].next) n = seed_emit(P.tasks[t], P.pool, out, n, cap, overflow);
+	int head = -1, last = -1;
+	for (int k = 0; k < n; ++k) {
+		const Biv p = out[k];
+		const int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
+		if (end - start < OPT_SPLIT_LEN || p.s > (uint64_t)OPT_SPLIT_WIDTH) continue;
+		const int x = (start + end) >> 1;
+		if (q[x] > 3) continue; // bwt_smem1a returns at once on an ambiguous base
+		const int t = ARX_ATOMIC_ADD(P.cursors + 1, 1);
+		if (t >= P.task_cap) { ARX_ATOMIC_OR(P.err, ERR_POOL_OVERFLOW); break; }
+		SeedTask kx; kx.read = read; kx.x = x; kx.min_intv = (int)p.s + 1; kx.off = 0; kx.n = 0; kx.nm = 0; kx.next = -1; kx.pad = 0;
+		P.tasks[t] = kx;
+		if (last >= 0) P.tasks[last].next = t; else head = t;
+		last = t;
+	}
+	*first2 = head;
+	return n;
+}
+ARX_DEV int seed_gather_pass2(const SeedPools &P, int first2, Biv *out, int n, int cap, int *overflow)
+{
+	for (int t = first2; t >= 0; t = P.tasks[t].next) if (P.tasks[t].n > 0) n = seed_emit(P.tasks[t], P.pool, out, n, cap, overflow);
+	return n;
+}
 
 // Third pass of mem_collect_intv: bwt_seed_strategy1 (bwt.c:358-379) from every position a match can start at -- the
 // shortest forward match longer than min_seed_len that occurs fewer than max_mem_intv times.  It does not look at the

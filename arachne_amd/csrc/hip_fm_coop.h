@@ -45,32 +45,29 @@ static __global__ void __launch_bounds__(256) k_locate_dyn(IndexView ix, Seed *o
 	}
 }
 
-// k_seed_dyn / k_strat_dyn: the seeding passes of mem_collect_intv with persistent lanes.  A read's SMEM search is a serial
-// chain of several hundred bidirectional extensions whose count varies a lot between reads (repeats), so a static
-// one-read-per-lane mapping makes every wavefront wait for its slowest read.  Here a lane takes its next read as soon as the
-// previous one is finished (wave-level chunk reservation as in k_locate_dyn), and every iteration of the loop is one
-// extension for all busy lanes: the lane program (SeedLane / StratLane, dev_fm.h) runs each lane's bookkeeping up to its next
-// extension, the lanes reconverge on extend1().  The read's bases are staged in LDS (4-bit codes, row stride 33 words so
-// that the 64 lanes hit different banks): the search reads one base per extension, which would otherwise be a dependent HBM
-// access in front of the Occ block loads.
+// Persistent-lane kernels of the seeding passes (mem_collect_intv).  A read's SMEM search is a serial chain of several
+// hundred bidirectional extensions whose count varies a lot between reads (repeats), so a static one-item-per-lane mapping
+// makes every wavefront wait for its slowest item.  Here a lane takes its next item (a read, or a forward / backward task,
+// dev_fm.h) as soon as the previous one is finished: a wave reserves chunks of the item range with ONE atomic and deals them
+// out to its idle lanes by ballot rank.  Every iteration of the loop is one extension for all busy lanes: the lane program
+// runs each lane's bookkeeping up to its next extension, the lanes reconverge on extend1() (two random 64-byte Occ blocks).
+// The item's read is staged in LDS (4-bit codes, row stride 33 words so that the 64 lanes hit different banks): a search
+// reads one base per extension, which would otherwise be a dependent HBM access in front of the Occ block loads.
+// What happens between two runs of extensions (exporting a finished forward list, taking the next start or item) is rare per
+// lane but long, and a wavefront pays for a divergent path whenever ONE lane is in it; lanes therefore wait in front of it
+// until `batch` of them do (or nobody can extend), and the wave runs that code once for all of them.
 constexpr int SEED_ROW = 132; // bytes per lane: 256 bases + pad
 
-struct SeedArgs {
-	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens;
-	Biv *intv; int32_t *n_intv; Biv *scratch; int list_cap; uint32_t *err;
-};
-struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; };
-
-// Hands reads to idle lanes: a wave reserves `chunk` reads with one atomic and deals them out by ballot rank; the wave then
-// copies the bases of every newly taken read into the taking lane's LDS row.  r < 0 marks an idle lane.  Returns false when
-// nothing is left and the whole wave is idle.
-struct ReadFeeder {
+struct ItemFeeder {
 	int pool_next = 0, pool_end = 0; bool exhausted = false; // wave-uniform
-	__device__ bool deal(int &r, bool &took, const uint8_t *bases, const int32_t *base_off, const int32_t *lens, int n, int32_t *counter, int chunk, uint8_t *q_lds)
+	// item < 0 marks an idle lane.  tasks != nullptr: items are task ids (t0 + item), the read to stage is the task's.
+	// Returns false when nothing is left and the whole wave is idle.
+	__device__ bool deal(int &item, bool &took, const SeedTask *tasks, int t0, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
+	                     int n, int32_t *counter, int chunk, uint8_t *q_lds)
 	{
 		const int lane = threadIdx.x;
 		took = false;
-		const unsigned long long idle = __ballot(r < 0);
+		const unsigned long long idle = __ballot(item < 0);
 		if (!idle) return true;
 		if (pool_next == pool_end && !exhausted) {
 			int base = 0;
@@ -82,15 +79,16 @@ struct ReadFeeder {
 		const int avail = pool_end - pool_next;
 		if (avail <= 0) return !(exhausted && idle == ~0ull); // every wave is 64 lanes wide here
 		const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
-		took = r < 0 && rank < avail;
-		if (took) r = pool_next + rank;
+		took = item < 0 && rank < avail;
+		if (took) item = pool_next + rank;
 		const int need = __builtin_popcountll(idle);
 		pool_next += need < avail ? need : avail;
 		unsigned long long fresh = __ballot(took);
-		while (fresh) { // 128 bases per sweep of the wave
+		while (fresh) { // the wave copies the read of every newly taken item into the taking lane's LDS row, 128 bases per sweep
 			const int src = __builtin_ctzll(fresh);
 			fresh &= fresh - 1;
-			const int rs = __shfl(r, src);
+			const int it = __shfl(item, src);
+			const int rs = tasks ? tasks[t0 + it].read : it;
 			const int len = lens[rs];
 			const uint8_t *b = bases + base_off[rs];
 			if (len <= MAX_READ_LEN)
@@ -106,46 +104,133 @@ struct ReadFeeder {
 	}
 };
 
-static __global__ void __launch_bounds__(64) k_seed_dyn(SeedArgs A, int n, int32_t *counter, int batch, int chunk)
+struct SeedKArgs { // shared by the three kernels
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int32_t *first1; int t0;
+};
+
+// Lane programs: begin(item) after the read is staged (false: nothing to do), advance(req, rb, rc, slow_ok) -> has a request /
+// parked or done, consume(req, ok), done(), finish().
+struct FwdProg1 { // first pass: the forward extensions of one read, start after start
+	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last; bool extending, over;
+	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), extending(false), over(true) {}
+	__device__ bool begin(int item)
+	{
+		r = item; len = A.lens[r]; x = 0; head = last = -1; extending = false; over = false;
+		if (len > MAX_READ_LEN) { atomicOr(A.P.err, ERR_READ_TOO_LONG); len = 0; }
+		if (len < OPT_MIN_SEED_LEN) { A.first1[r] = -1; over = true; return false; }
+		return true;
+	}
+	__device__ bool advance(Biv *req, int *rb, int *rc, bool slow_ok)
+	{
+		*rb = 0;
+		while (!over) {
+			if (extending) {
+				if (ln.advance(req, rc)) return true;
+				if (!slow_ok) return false;
+				const int t = seed_export(A.P, r, x, 1, list, ln.n); // the forward list becomes a backward task
+				if (t < 0) { over = true; break; }
+				if (last >= 0) A.P.tasks[last].next = t; else head = t;
+				last = t;
+				x = ln.ret();
+				extending = false;
+			}
+			if (!slow_ok) return false;
+			while (x < len && q.at(x) > 3) ++x;
+			if (x >= len) { over = true; break; }
+			ln.start(A.ix, len, q, x, 1, list);
+			extending = true;
+		}
+		return false;
+	}
+	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
+	__device__ bool done() const { return over; }
+	__device__ void finish() { A.first1[r] = head; }
+};
+
+struct FwdProg2 { // re-seeding: the forward extension of one task
+	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int t; bool over;
+	__device__ FwdProg2(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), t(-1), over(true) {}
+	__device__ bool begin(int item)
+	{
+		t = A.t0 + item;
+		const SeedTask k = A.P.tasks[t];
+		ln.start(A.ix, A.lens[k.read], q, k.x, k.min_intv, list);
+		over = false;
+		return true;
+	}
+	__device__ bool advance(Biv *req, int *rb, int *rc, bool slow_ok)
+	{
+		*rb = 0;
+		if (over) return false;
+		if (ln.advance(req, rc)) return true;
+		if (!slow_ok) return false;
+		seed_export_into(A.P, t, list, ln.n);
+		over = true;
+		return false;
+	}
+	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
+	__device__ bool done() const { return over; }
+	__device__ void finish() {}
+};
+
+struct BwdProg { // the backward sweep of one task
+	const SeedKArgs &A; QNibbles q; BwdLane<QNibbles> ln; int t;
+	__device__ BwdProg(const SeedKArgs &a, Biv *, QNibbles qq) : A(a), q(qq), t(-1) { ln.finished = true; }
+	__device__ bool begin(int item)
+	{
+		t = A.t0 + item;
+		const SeedTask k = A.P.tasks[t];
+		if (k.n == 0) { ln.finished = true; return false; }
+		ln.start(q, k, A.P.pool);
+		return true;
+	}
+	__device__ bool advance(Biv *req, int *rb, int *rc, bool) { *rb = 1; return ln.advance(req, rc); }
+	__device__ void consume(const Biv &req, const Biv &ok) { ln.consume(req, ok); }
+	__device__ bool done() const { return ln.finished; }
+	__device__ void finish() { A.P.tasks[t].nm = ln.nm; }
+};
+
+template <class Prog, bool BY_TASK>
+__device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int32_t *counter, int batch, int chunk, uint8_t *q_lds)
 {
-	__shared__ uint8_t q_lds[64 * SEED_ROW];
 	const int lane = threadIdx.x;
-	const int slot = blockIdx.x * 64 + lane;
-	SmemScratch sc; sc.v0 = A.scratch + (size_t)slot * 3 * A.list_cap; sc.v1 = sc.v0 + A.list_cap; sc.mem = sc.v1 + A.list_cap;
-	SeedLane<QNibbles> ln;
-	ln.state = SeedLane<QNibbles>::ST_DONE;
-	ReadFeeder feed;
-	int r = -1; // read this lane is searching, -1 = idle
+	Prog prog(A, A.scratch + (size_t)(blockIdx.x * 64 + lane) * A.list_cap, QNibbles{q_lds + lane * SEED_ROW});
+	ItemFeeder feed;
+	int item = -1; // what this lane is working on, -1 = idle
 	Biv req = Biv();
 	int rb = 0, rc = 0;
 	bool have_req = false;
 	for (;;) {
-		// cheap part: a lane whose search is in an extending state gets its next request
-		if (r >= 0 && !have_req) have_req = ln.advance(A.ix, &req, &rb, &rc, false);
-		// The rest (finishing a read, taking the next one, the bookkeeping between two searches) is rare per lane but long, and
-		// a wavefront pays for a divergent path whenever ONE lane is in it.  Lanes therefore wait in front of it until `batch`
-		// of them do (or nobody can extend): the wave then runs that code once for all of them.
+		if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, false); // cheap part: the next request of a running extension
 		const int waiting = __builtin_popcountll(__ballot(!have_req));
 		if (waiting >= batch || waiting == 64) {
-			if (r >= 0 && !have_req && ln.done()) { // a finished read: its interval count (the third pass and the sort follow in their own kernels)
-				A.n_intv[r] = ln.n;
-				if (ln.overflow) atomicOr(A.err, ERR_INTV_OVERFLOW);
-				r = -1;
-			}
+			if (item >= 0 && !have_req && prog.done()) { prog.finish(); item = -1; }
 			bool took;
-			if (!feed.deal(r, took, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
-			if (took) {
-				int len = A.lens[r];
-				if (len > MAX_READ_LEN) { atomicOr(A.err, ERR_READ_TOO_LONG); len = 0; }
-				if (len >= OPT_MIN_SEED_LEN) ln.start(sc, len, QNibbles{q_lds + lane * SEED_ROW}, A.intv + (size_t)r * CAP_INTV, CAP_INTV);
-				else { A.n_intv[r] = 0; r = -1; } // nothing to seed; the lane asks again next time round
-			}
-			// everything up to the next request (a read that ends here is written out the next time round)
-			if (r >= 0 && !have_req) have_req = ln.advance(A.ix, &req, &rb, &rc, true);
+			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
+			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
+			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
 		}
-		if (have_req) { ln.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
+		if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}
 }
+
+static __global__ void __launch_bounds__(64) k_seed_fwd1(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+{
+	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	persistent_lanes<FwdProg1, false>(A, n, counter, batch, chunk, q_lds);
+}
+static __global__ void __launch_bounds__(64) k_seed_fwd2(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+{
+	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	persistent_lanes<FwdProg2, true>(A, n, counter, batch, chunk, q_lds);
+}
+static __global__ void __launch_bounds__(64) k_seed_bwd(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+{
+	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	persistent_lanes<BwdProg, true>(A, n, counter, batch, chunk, q_lds);
+}
+
+struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; };
 
 // third pass: forward extensions only, no lists -- the loop body is little more than extend1()
 static __global__ void __launch_bounds__(64) k_strat_dyn(StratArgs A, int n, int32_t *counter, int chunk)
@@ -154,12 +239,12 @@ static __global__ void __launch_bounds__(64) k_strat_dyn(StratArgs A, int n, int
 	const int lane = threadIdx.x;
 	StratLane<QNibbles> ln;
 	ln.finished = true;
-	ReadFeeder feed;
+	ItemFeeder feed;
 	int r = -1;
 	for (;;) {
 		if (__ballot(r < 0)) {
 			bool took;
-			if (!feed.deal(r, took, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
+			if (!feed.deal(r, took, nullptr, 0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
 			if (took) {
 				const int len = A.lens[r];
 				if (len >= OPT_MIN_SEED_LEN && len <= MAX_READ_LEN) ln.start(len, QNibbles{q_lds + lane * SEED_ROW}, A.strat + (size_t)r * CAP_STRAT);

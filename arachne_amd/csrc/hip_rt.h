@@ -205,19 +205,38 @@ struct HipRT {
 		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
-	// seeding: persistent lanes, reads handed out in chunks (hip_fm_coop.h); f is pipeline.h's KSeed, f.scratch holds max_slots() list triples
-	template <class F> void run_seed(const char *nm, int n, const F &f, int32_t *counter)
+	// seeding: persistent lanes, items handed out in chunks (hip_fm_coop.h); f is one of pipeline.h's KSeedFwd1 / KSeedFwd2 / KSeedBwd,
+	// f.scratch holds max_slots() forward lists
+	int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 16; // lanes that queue up before the slow bookkeeping runs
+	int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64; // items a wavefront reserves per atomic
+	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_)
+	{
+		memset0(counter, 4);
+		Scope sc(*this, nm, n);
+		int blocks = (n + 63) / 64; if (blocks > n_cu * bpc_) blocks = n_cu * bpc_;
+		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_batch, seed_chunk);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
+	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *counter)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		memset0(counter, 4);
-		Scope sc(*this, nm, n);
-		SeedArgs A{f.ix, f.bases, f.base_off, f.lens, f.intv, f.n_intv, f.scratch, f.list_cap, f.err};
-		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
-		static const int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 16; // lanes that queue up before the slow bookkeeping runs
-		static const int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64;  // reads a wavefront reserves per atomic
-		hipLaunchKernelGGL(k_seed_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_batch, seed_chunk);
-		ARX_HIP_CHECK(hipGetLastError());
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0};
+		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, bpc);
+	}
+	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *counter)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch(nm, n, f); return; }
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0};
+		launch_seed_kernel(nm, k_seed_fwd2, n, A, counter, bpc);
+	}
+	template <class F> void run_seed_bwd(const char *nm, int n, const F &f, int32_t *counter)
+	{
+		if (n <= 0) return;
+		if (sw_simple) { launch(nm, n, f); return; }
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0};
+		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, bpc);
 	}
 	template <class F> void run_seed_strat(const char *nm, int n, const F &f, int32_t *counter)
 	{
@@ -226,7 +245,6 @@ struct HipRT {
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
 		StratArgs A{f.ix, f.bases, f.base_off, f.lens, f.strat, f.n_strat};
-		static const int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64;
 		int blocks = (n + 63) / 64; if (blocks > n_cu * strat_bpc) blocks = n_cu * strat_bpc;
 		hipLaunchKernelGGL(k_strat_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_chunk);
 		ARX_HIP_CHECK(hipGetLastError());

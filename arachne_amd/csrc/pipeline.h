@@ -22,26 +22,88 @@
 namespace arx {
 
 // ---------------------------------------------------------------- kernel functors (item = work unit, slot = scratch slot)
-struct KSeed { // passes 1 and 2 of mem_collect_intv for one read (the HIP runtime drives SeedLane with persistent lanes instead, hip_fm_coop.h)
-	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens;
-	Biv *intv; int32_t *n_intv; Biv *scratch; int list_cap; uint32_t *err;
+// ---- first two passes of mem_collect_intv as forward / backward tasks (dev_fm.h).  These functors run one item per thread; the
+// HIP runtime drives the same lane programs with persistent lanes instead (hip_fm_coop.h).
+struct KSeedFwd1 { // first pass, forward halves: the starts of a read chain through bwt_smem1a's return value
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int32_t *first1;
 	ARX_DEV void operator()(int r, int slot) const
 	{
-		int len = lens[r], n = 0;
-		if (len > MAX_READ_LEN) { atomic_or_err(err, ERR_READ_TOO_LONG); len = 0; }
+		int len = lens[r], head = -1, last = -1;
+		if (len > MAX_READ_LEN) { atomic_or_err(P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len >= OPT_MIN_SEED_LEN) {
-			SmemScratch sc; sc.v0 = scratch + (size_t)slot * 3 * list_cap; sc.v1 = sc.v0 + list_cap; sc.mem = sc.v1 + list_cap;
-			SeedLane<QBytes> ln;
-			ln.start(sc, len, QBytes{bases + base_off[r]}, intv + (size_t)r * CAP_INTV, CAP_INTV);
-			Biv req = Biv();
-			int rb = 0, rc = 0;
-			while (ln.advance(ix, &req, &rb, &rc)) ln.consume(req, extend1(ix, req, rb, rc));
-			if (ln.overflow) atomic_or_err(err, ERR_INTV_OVERFLOW);
-			n = ln.n;
+			const QBytes q{bases + base_off[r]};
+			Biv *list = scratch + (size_t)slot * list_cap;
+			for (int x = 0;;) {
+				while (x < len && q.at(x) > 3) ++x;
+				if (x >= len) break;
+				FwdLane<QBytes> ln;
+				ln.start(ix, len, q, x, 1, list);
+				Biv req = Biv();
+				int rc = 0;
+				while (ln.advance(&req, &rc)) ln.consume(extend1(ix, req, 0, rc));
+				const int t = seed_export(P, r, x, 1, list, ln.n);
+				if (t < 0) break;
+				if (last >= 0) P.tasks[last].next = t; else head = t;
+				last = t;
+				x = ln.ret();
+			}
 		}
-		n_intv[r] = n;
+		first1[r] = head;
 	}
 	static ARX_DEVI void atomic_or_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); }
+};
+typedef KSeedFwd1 KSeed; // error helper used by other functors
+
+struct KSeedBwd { // the backward sweep of task t0 + item
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; int t0;
+	ARX_DEV void operator()(int item, int) const
+	{
+		SeedTask t = P.tasks[t0 + item];
+		if (t.n == 0) return;
+		BwdLane<QBytes> ln;
+		ln.start(QBytes{bases + base_off[t.read]}, t, P.pool);
+		Biv req = Biv();
+		int rc = 0;
+		while (ln.advance(&req, &rc)) ln.consume(req, extend1(ix, req, 1, rc));
+		P.tasks[t0 + item].nm = ln.nm;
+	}
+};
+
+struct KSeedGather1 {
+	const uint8_t *bases; const int32_t *base_off; SeedPools P; const int32_t *first1; Biv *intv; int32_t *n_intv, *first2;
+	ARX_DEV void operator()(int r, int) const
+	{
+		int ovf = 0, f2 = -1;
+		n_intv[r] = seed_gather_pass1(P, r, first1[r], bases + base_off[r], intv + (size_t)r * CAP_INTV, CAP_INTV, &ovf, &f2);
+		first2[r] = f2;
+		if (ovf) KSeed::atomic_or_err(P.err, ERR_INTV_OVERFLOW);
+	}
+};
+
+struct KSeedFwd2 { // forward half of re-seeding task t0 + item; its pool slice is reserved once the list length is known
+	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int t0;
+	ARX_DEV void operator()(int item, int slot) const
+	{
+		SeedTask t = P.tasks[t0 + item];
+		const QBytes q{bases + base_off[t.read]};
+		Biv *list = scratch + (size_t)slot * list_cap;
+		FwdLane<QBytes> ln;
+		ln.start(ix, lens[t.read], q, t.x, t.min_intv, list);
+		Biv req = Biv();
+		int rc = 0;
+		while (ln.advance(&req, &rc)) ln.consume(extend1(ix, req, 0, rc));
+		seed_export_into(P, t0 + item, list, ln.n);
+	}
+};
+
+struct KSeedGather2 {
+	SeedPools P; const int32_t *first2; Biv *intv; int32_t *n_intv;
+	ARX_DEV void operator()(int r, int) const
+	{
+		int ovf = 0;
+		n_intv[r] = seed_gather_pass2(P, first2[r], intv + (size_t)r * CAP_INTV, n_intv[r], CAP_INTV, &ovf);
+		if (ovf) KSeed::atomic_or_err(P.err, ERR_INTV_OVERFLOW);
+	}
 };
 
 struct KSeedStrat { // pass 3 for one read
@@ -306,6 +368,7 @@ public:
 	RT &rt;
 	IndexView ix;
 	bool trace = getenv("ARX_TRACE") != nullptr; // per-round progress on stderr
+	int seed_pool_per_read = getenv("ARX_SEED_POOL") ? atoi(getenv("ARX_SEED_POOL")) : 384; // interval-pool entries per read (3 per forward-list entry); an overflow is reported, never silent
 	explicit Pipeline(RT &rt_, const IndexView &ix_) : rt(rt_), ix(ix_) {}
 
 	// device-resident input of one batch
@@ -359,12 +422,34 @@ public:
 		w.err = rt.template alloc<uint32_t>(4); rt.memset0(w.err, 16);
 		w.counter = rt.template alloc<int32_t>(4);
 		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);
-		w.smem_scr = rt.template alloc<Biv>((size_t)slots * 3 * list_cap);
+		w.smem_scr = rt.template alloc<Biv>((size_t)slots * list_cap); // one forward list per resident lane
 		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
 		Biv *strat = rt.template alloc<Biv>((size_t)R * CAP_STRAT);
 		int32_t *n_strat = rt.template alloc<int32_t>(R + 1);
-		KSeed k{ix, b.bases, b.base_off, b.lens, w.intv, w.n_intv, w.smem_scr, list_cap, w.err};
-		rt.run_seed("seed", R, k, w.counter);
+		// first two passes: forward chains -> backward tasks -> gather + re-seeding tasks -> their forward and backward halves -> gather
+		SeedPools P;
+		P.pool_cap = (int64_t)R * seed_pool_per_read; P.task_cap = (int32_t)((int64_t)R * 12 < 0x7fffffff ? R * 12 : 0x7fffffff);
+		P.pool = rt.template alloc<Biv>((size_t)P.pool_cap + 1); P.tasks = rt.template alloc<SeedTask>((size_t)P.task_cap + 1);
+		P.cursors = rt.template alloc<int32_t>(2); P.err = w.err;
+		rt.memset0(P.cursors, 8);
+		int32_t *first1 = rt.template alloc<int32_t>(R + 1), *first2 = rt.template alloc<int32_t>(R + 1);
+		int32_t cur[2];
+		KSeedFwd1 kf{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, first1};
+		rt.run_seed_fwd1("seed_fwd", R, kf, w.counter);
+		rt.d2h(cur, P.cursors, 8);
+		const int n1 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
+		KSeedBwd kb{ix, b.bases, b.base_off, b.lens, P, 0};
+		rt.run_seed_bwd("seed_bwd", n1, kb, w.counter);
+		KSeedGather1 kg1{b.bases, b.base_off, P, first1, w.intv, w.n_intv, first2};
+		rt.launch("seed_gather", R, kg1);
+		rt.d2h(cur, P.cursors, 8);
+		const int n2 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
+		KSeedFwd2 kf2{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, n1};
+		rt.run_seed_fwd2("seed_fwd", n2 - n1, kf2, w.counter);
+		kb.t0 = n1;
+		rt.run_seed_bwd("seed_bwd", n2 - n1, kb, w.counter);
+		KSeedGather2 kg2{P, first2, w.intv, w.n_intv};
+		rt.launch("seed_gather", R, kg2);
 		KSeedStrat k3{ix, b.bases, b.base_off, b.lens, strat, n_strat};
 		rt.run_seed_strat("seed_strat", R, k3, w.counter);
 		KSeedMerge km{w.intv, w.n_intv, strat, n_strat, w.n_occ, w.err};

@@ -103,7 +103,9 @@ struct SimRT {
 	template <class F> void launch_block(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; SimBlock blk; for (int i = 0; i < n; ++i) f(i, blk); }
 	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
-	template <class F> void run_seed(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
+	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
+	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
+	template <class F> void run_seed_bwd(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
 	template <class F> void run_seed_strat(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
 	template <class F> void run_locate(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
 	template <class F> void run_extend(const char *nm, const int32_t *n_class, int stride, const F &f)
