@@ -237,14 +237,18 @@ ARX_DEVI void seed_export_into(const SeedPools &P, int t, const Biv *list, int n
 	P.tasks[t].off = off; P.tasks[t].n = n;
 }
 
-// backward half of bwt_smem1a (bwt.c:323-349) for one task
+// backward half of bwt_smem1a (bwt.c:323-349) for one task.  Most rows of a sweep hold a single interval (a unique match
+// narrows to one size quickly): entry 0 of both lists therefore lives in registers only (prev0 / curr0) and such rows touch
+// no list memory at all; entries 1.. go through the task's pool slice.
 template <class Q> struct BwdLane {
 	Q q; Biv *prev, *curr, *mem; int min_intv, i, j, c, n_prev, n_curr, nm, mem_last_start; bool finished, in_row;
 	uint64_t curr_last_s; // curr[n_curr - 1].s and the start of mem[nm - 1] are kept in registers: both are looked at after every extension
+	Biv prev0, curr0;
 	ARX_DEVI void start(const Q &q_, const SeedTask &t, Biv *pool)
 	{
 		q = q_; prev = pool + t.off; curr = prev + t.n; mem = curr + t.n; min_intv = t.min_intv;
 		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
+		prev0 = prev[0]; curr0 = Biv();
 	}
 	ARX_DEVI bool advance(Biv *req, int *rc)
 	{
@@ -254,7 +258,7 @@ template <class Q> struct BwdLane {
 				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
 				n_curr = 0; j = 0;
 				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
-					if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev[0]; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
+					if (n_prev > 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = prev0; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
 					finished = true;
 					break;
 				}
@@ -262,11 +266,11 @@ template <class Q> struct BwdLane {
 			}
 			if (j >= n_prev) {
 				if (n_curr == 0) { finished = true; break; }
-				Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+				Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr; prev0 = curr0;
 				--i; in_row = false;
 				continue;
 			}
-			*req = prev[j]; *rc = c;
+			*req = j == 0 ? prev0 : prev[j]; *rc = c;
 			return true;
 		}
 		return false;
@@ -277,7 +281,8 @@ template <class Q> struct BwdLane {
 			if (n_curr == 0 && (nm == 0 || i + 1 < mem_last_start)) { Biv t = req; t.info |= (uint64_t)(i + 1) << 32; mem[nm++] = t; mem_last_start = i + 1; }
 		} else if (n_curr == 0 || ok.s != curr_last_s) {
 			Biv t = ok; t.info = req.info;
-			curr[n_curr++] = t; curr_last_s = ok.s;
+			if (n_curr == 0) curr0 = t; else curr[n_curr] = t;
+			++n_curr; curr_last_s = ok.s;
 		}
 		++j;
 	}

@@ -109,13 +109,16 @@ struct SeedKArgs { // shared by the three kernels
 };
 
 // Lane programs: begin(item) after the read is staged (false: nothing to do), advance(req, rb, rc, slow_ok) -> has a request /
-// parked or done, consume(req, ok), done(), finish().
+// parked or done, consume(req, ok), done(), finish().  A program that needs pool entries (and a task id) parks with want() > 0;
+// the driver serves all such lanes of the wave with ONE atomic per cursor (a per-lane atomic on the batch-wide cursors was the
+// bottleneck of the forward kernels) and calls granted().
 struct FwdProg1 { // first pass: the forward extensions of one read, start after start
-	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last; bool extending, over;
-	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), extending(false), over(true) {}
+	static constexpr bool ALLOCATES = true, NEW_TASK = true;
+	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last; bool extending, awaiting, over;
+	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), extending(false), awaiting(false), over(true) {}
 	__device__ bool begin(int item)
 	{
-		r = item; len = A.lens[r]; x = 0; head = last = -1; extending = false; over = false;
+		r = item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false;
 		if (len > MAX_READ_LEN) { atomicOr(A.P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len < OPT_MIN_SEED_LEN) { A.first1[r] = -1; over = true; return false; }
 		return true;
@@ -123,16 +126,12 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 	__device__ bool advance(Biv *req, int *rb, int *rc, bool slow_ok)
 	{
 		*rb = 0;
-		while (!over) {
+		while (!over && !awaiting) {
 			if (extending) {
 				if (ln.advance(req, rc)) return true;
 				if (!slow_ok) return false;
-				const int t = seed_export(A.P, r, x, 1, list, ln.n); // the forward list becomes a backward task
-				if (t < 0) { over = true; break; }
-				if (last >= 0) A.P.tasks[last].next = t; else head = t;
-				last = t;
-				x = ln.ret();
-				extending = false;
+				awaiting = true; // the forward list becomes a backward task once its pool slice is granted
+				break;
 			}
 			if (!slow_ok) return false;
 			while (x < len && q.at(x) > 3) ++x;
@@ -142,31 +141,52 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 		}
 		return false;
 	}
+	__device__ int want() const { return awaiting ? 3 * ln.n : 0; }
+	__device__ void granted(int off, int t)
+	{
+		awaiting = false; extending = false;
+		if (t >= A.P.task_cap || (int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); over = true; return; }
+		SeedTask k; k.read = r; k.x = x; k.min_intv = 1; k.off = off; k.n = ln.n; k.nm = 0; k.next = -1; k.pad = 0;
+		A.P.tasks[t] = k;
+		Biv *dst = A.P.pool + off;
+		for (int e = 0; e < ln.n; ++e) dst[e] = list[ln.n - 1 - e]; // longest first (bwt.c:322)
+		if (last >= 0) A.P.tasks[last].next = t; else head = t;
+		last = t;
+		x = ln.ret();
+	}
 	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
 	__device__ bool done() const { return over; }
 	__device__ void finish() { A.first1[r] = head; }
 };
 
 struct FwdProg2 { // re-seeding: the forward extension of one task
-	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int t; bool over;
-	__device__ FwdProg2(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), t(-1), over(true) {}
+	static constexpr bool ALLOCATES = true, NEW_TASK = false;
+	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int t; bool awaiting, over;
+	__device__ FwdProg2(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), t(-1), awaiting(false), over(true) {}
 	__device__ bool begin(int item)
 	{
 		t = A.t0 + item;
 		const SeedTask k = A.P.tasks[t];
 		ln.start(A.ix, A.lens[k.read], q, k.x, k.min_intv, list);
-		over = false;
+		over = false; awaiting = false;
 		return true;
 	}
 	__device__ bool advance(Biv *req, int *rb, int *rc, bool slow_ok)
 	{
 		*rb = 0;
-		if (over) return false;
+		if (over || awaiting) return false;
 		if (ln.advance(req, rc)) return true;
-		if (!slow_ok) return false;
-		seed_export_into(A.P, t, list, ln.n);
-		over = true;
+		if (slow_ok) awaiting = true;
 		return false;
+	}
+	__device__ int want() const { return awaiting ? 3 * ln.n : 0; }
+	__device__ void granted(int off, int)
+	{
+		awaiting = false; over = true;
+		if ((int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); return; } // n stays 0: the task is skipped
+		Biv *dst = A.P.pool + off;
+		for (int e = 0; e < ln.n; ++e) dst[e] = list[ln.n - 1 - e];
+		A.P.tasks[t].off = off; A.P.tasks[t].n = ln.n;
 	}
 	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
 	__device__ bool done() const { return over; }
@@ -174,6 +194,7 @@ struct FwdProg2 { // re-seeding: the forward extension of one task
 };
 
 struct BwdProg { // the backward sweep of one task
+	static constexpr bool ALLOCATES = false, NEW_TASK = false;
 	const SeedKArgs &A; QNibbles q; BwdLane<QNibbles> ln; int t;
 	__device__ BwdProg(const SeedKArgs &a, Biv *, QNibbles qq) : A(a), q(qq), t(-1) { ln.finished = true; }
 	__device__ bool begin(int item)
@@ -185,6 +206,8 @@ struct BwdProg { // the backward sweep of one task
 		return true;
 	}
 	__device__ bool advance(Biv *req, int *rb, int *rc, bool) { *rb = 1; return ln.advance(req, rc); }
+	__device__ int want() const { return 0; }
+	__device__ void granted(int, int) {}
 	__device__ void consume(const Biv &req, const Biv &ok) { ln.consume(req, ok); }
 	__device__ bool done() const { return ln.finished; }
 	__device__ void finish() { A.P.tasks[t].nm = ln.nm; }
@@ -209,6 +232,26 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
+			if (Prog::ALLOCATES) { // pool slices (and task ids) for every lane that parked for them: one atomic per cursor and wave
+				const int amt = (item >= 0 && !have_req) ? prog.want() : 0;
+				const unsigned long long askers = __ballot(amt > 0);
+				if (askers) {
+					int incl = amt;
+					for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+					const int total = __shfl(incl, 63);
+					int base = 0, tbase = 0;
+					if (lane == 0) {
+						base = atomicAdd(A.P.cursors, total);
+						if (Prog::NEW_TASK) tbase = atomicAdd(A.P.cursors + 1, __builtin_popcountll(askers));
+					}
+					base = __shfl(base, 0); tbase = __shfl(tbase, 0);
+					const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(askers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)askers, 0));
+					if (amt > 0) {
+						prog.granted(base + incl - amt, tbase + rank);
+						have_req = prog.advance(&req, &rb, &rc, true); // on to the next start
+					}
+				}
+			}
 		}
 		if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}

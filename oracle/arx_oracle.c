@@ -316,7 +316,7 @@ static void extend(const index_t *ix, const biv_t *ik, biv_t ok[4], int is_back,
 	occ4(ix, k, tk); occ4(ix, l, tl);
 	if (cnt) {
 		uint64_t _k = k - (k >= ix->primary), _l = l - (l >= ix->primary);
-		if (_l >> 7 != _k >> 7 || k == (uint64_t)-1 || l == (uint64_t)-1) ++cnt->ext_two_block; else ++cnt->ext_same_block;
+		if (_l >> 7 != _k >> 7 || k == (uint64_t)-1 || l == (uint64_t)-1) { ++cnt->ext_two_block; cnt->extb_two_block += is_back; } else { ++cnt->ext_same_block; cnt->extb_same_block += is_back; }
 	}
 	for (i = 0; i < 4; ++i) {
 		uint64_t na = ix->L2[i] + 1 + tk[i];
@@ -455,6 +455,7 @@ static void bv_reverse(bivec_t *v)
 
 static int smem1(const index_t *ix, int len, const uint8_t *q, int x, int min_intv, bivec_t *mem, bivec_t *v0, bivec_t *v1, ora_counters_t *cnt)
 {
+	if (cnt) ++cnt->n_smem_calls;
 	int i, j, c, ret;
 	biv_t ik, ok[4];
 	bivec_t *prev = v0, *curr = v1, *sw;
