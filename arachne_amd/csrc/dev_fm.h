@@ -174,7 +174,11 @@ ARX_DEVI uint64_t sa_lookup(const IndexView &ix, uint64_t k)
 struct QBytes { const uint8_t *p; ARX_DEVI int at(int i) const { return p[i]; } };       // base codes 0..4, one per byte
 struct QNibbles { const uint8_t *p; ARX_DEVI int at(int i) const { return (p[i >> 1] >> ((i & 1) << 2)) & 15; } }; // two per byte (LDS staging)
 
-struct SeedTask { int32_t read, x, min_intv, off, n, nm, next, pad; }; // off/n: pool slice; nm: SMEMs found; next: the read's next task (-1: last)
+struct SeedTask { // off/n: pool slice; nm: SMEMs found; next: the read's next task (-1: last)
+	int32_t read, x, min_intv, off, n, nm, next;
+	int32_t flip;               // a sweep handed over at a row boundary (hip_fm_coop.h): 1 if the lists have changed places,
+	int32_t row, n_prev, mls, pad; // the row to go on with, the entries of its list, the start of the last SMEM found
+};
 
 struct SeedPools { // batch-wide, filled through atomic cursors; an overflow raises ERR_POOL_OVERFLOW and the read yields no more tasks
 	Biv *pool; int64_t pool_cap; SeedTask *tasks; int32_t task_cap; int32_t *cursors; // cursors[0]: pool entries handed out, [1]: tasks
@@ -184,7 +188,7 @@ struct SeedPools { // batch-wide, filled through atomic cursors; an overflow rai
 		const int t = ARX_ATOMIC_ADD(cursors + 1, 1);
 		const int off = ARX_ATOMIC_ADD(cursors, 3 * n);
 		if (t >= task_cap || (int64_t)off + 3 * n > pool_cap) { ARX_ATOMIC_OR(err, ERR_POOL_OVERFLOW); return -1; }
-		SeedTask k; k.read = read; k.x = x; k.min_intv = min_intv; k.off = off; k.n = n; k.nm = 0; k.next = -1; k.pad = 0;
+		SeedTask k = SeedTask(); k.read = read; k.x = x; k.min_intv = min_intv; k.off = off; k.n = n; k.nm = 0; k.next = -1;
 		tasks[t] = k;
 		return t;
 	}
@@ -244,17 +248,22 @@ template <class Q> struct BwdLane {
 	Q q; Biv *prev, *curr, *mem; int min_intv, i, j, c, n_prev, n_curr, nm, mem_last_start; bool finished, in_row;
 	uint64_t curr_last_s; // curr[n_curr - 1].s and the start of mem[nm - 1] are kept in registers: both are looked at after every extension
 	Biv prev0, curr0;
+	int n_done, handed; // extensions so far; 1: the sweep stopped at a row boundary for somebody else to go on with (state in *this)
 	ARX_DEVI void start(const Q &q_, const SeedTask &t, Biv *pool)
 	{
+		n_done = 0; handed = 0;
 		q = q_; prev = pool + t.off; curr = prev + t.n; mem = curr + t.n; min_intv = t.min_intv;
 		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
 		prev0 = prev[0]; curr0 = Biv();
 	}
-	ARX_DEVI bool advance(Biv *req, int *rc)
+	// budget > 0: after that many extensions the sweep stops at the next row boundary (handed = 1): a sweep over a repeat
+	// can be ten times longer than the typical one, and a lane that is alone with it keeps its whole wavefront waiting
+	ARX_DEVI bool advance(Biv *req, int *rc, int budget = 0)
 	{
 		while (!finished) {
 			if (!in_row) { // backward extension by query position i (-1 = before the read)
 				if (i < -1) { finished = true; break; }
+				if (budget > 0 && n_done >= budget) { prev[0] = prev0; handed = 1; finished = true; break; }
 				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
 				n_curr = 0; j = 0;
 				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained
@@ -284,7 +293,7 @@ template <class Q> struct BwdLane {
 			if (n_curr == 0) curr0 = t; else curr[n_curr] = t;
 			++n_curr; curr_last_s = ok.s;
 		}
-		++j;
+		++j; ++n_done;
 	}
 };
 
@@ -316,7 +325,7 @@ ARX_DEV int seed_gather_pass1(const SeedPools &P, int read, int first_task, cons
 		if (q[x] > 3) continue; // bwt_smem1a returns at once on an ambiguous base
 		const int t = ARX_ATOMIC_ADD(P.cursors + 1, 1);
 		if (t >= P.task_cap) { ARX_ATOMIC_OR(P.err, ERR_POOL_OVERFLOW); break; }
-		SeedTask kx; kx.read = read; kx.x = x; kx.min_intv = (int)p.s + 1; kx.off = 0; kx.n = 0; kx.nm = 0; kx.next = -1; kx.pad = 0;
+		SeedTask kx = SeedTask(); kx.read = read; kx.x = x; kx.min_intv = (int)p.s + 1; kx.off = 0; kx.n = 0; kx.nm = 0; kx.next = -1;
 		P.tasks[t] = kx;
 		if (last >= 0) P.tasks[last].next = t; else head = t;
 		last = t;

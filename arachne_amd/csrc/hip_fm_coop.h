@@ -106,6 +106,7 @@ struct ItemFeeder {
 
 struct SeedKArgs { // shared by the three kernels
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int32_t *first1; int t0;
+	int32_t *heavy; int32_t *n_heavy; int budget; // backward sweeps that exceed `budget` extensions are queued here for k_seed_bwd_wave
 };
 
 // Lane programs: begin(item) after the read is staged (false: nothing to do), advance(req, rb, rc, slow_ok) -> has a request /
@@ -146,7 +147,7 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 	{
 		awaiting = false; extending = false;
 		if (t >= A.P.task_cap || (int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); over = true; return; }
-		SeedTask k; k.read = r; k.x = x; k.min_intv = 1; k.off = off; k.n = ln.n; k.nm = 0; k.next = -1; k.pad = 0;
+		SeedTask k = SeedTask(); k.read = r; k.x = x; k.min_intv = 1; k.off = off; k.n = ln.n; k.nm = 0; k.next = -1;
 		A.P.tasks[t] = k;
 		Biv *dst = A.P.pool + off;
 		for (int e = 0; e < ln.n; ++e) dst[e] = list[ln.n - 1 - e]; // longest first (bwt.c:322)
@@ -205,13 +206,91 @@ struct BwdProg { // the backward sweep of one task
 		ln.start(q, k, A.P.pool);
 		return true;
 	}
-	__device__ bool advance(Biv *req, int *rb, int *rc, bool) { *rb = 1; return ln.advance(req, rc); }
+	__device__ bool advance(Biv *req, int *rb, int *rc, bool) { *rb = 1; return ln.advance(req, rc, A.budget); }
 	__device__ int want() const { return 0; }
 	__device__ void granted(int, int) {}
 	__device__ void consume(const Biv &req, const Biv &ok) { ln.consume(req, ok); }
 	__device__ bool done() const { return ln.finished; }
-	__device__ void finish() { A.P.tasks[t].nm = ln.nm; }
+	__device__ void finish()
+	{
+		SeedTask &k = A.P.tasks[t];
+		k.nm = ln.nm;
+		if (ln.handed) { // the rest of this sweep goes to a whole wavefront
+			k.flip = ln.prev != A.P.pool + k.off; k.row = ln.i; k.n_prev = ln.n_prev; k.mls = ln.mem_last_start;
+			A.heavy[atomicAdd(A.n_heavy, 1)] = t;
+		}
+	}
 };
+
+// The rest of a long backward sweep, one task per wavefront: the entries of a row are extended side by side (lane j takes
+// prev[j]), and what the serial loop does with the results in order (bwt.c:336-345: the first interval that falls below
+// min_intv before any survivor becomes an SMEM; a survivor is kept unless it has the size of the survivor before it) is
+// done with ballots and shuffles.  A row then costs two trips to HBM however many entries it has.
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) { return (uint64_t)__shfl((int)(v >> 32), src) << 32 | (uint32_t)__shfl((int)v, src); }
+
+static __global__ void __launch_bounds__(64) k_seed_bwd_wave(SeedKArgs A)
+{
+	__shared__ uint8_t q_lds[SEED_ROW];
+	const int lane = threadIdx.x;
+	const int n_heavy = *A.n_heavy;
+	for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+		const int t = A.heavy[h];
+		const SeedTask k = A.P.tasks[t];
+		const int len = A.lens[k.read];
+		const uint8_t *b = A.bases + A.base_off[k.read];
+		__builtin_amdgcn_wave_barrier();
+		for (int e = 2 * lane; e < len; e += 128) { const int lo = b[e], hi = e + 1 < len ? b[e + 1] : 4; q_lds[e >> 1] = (uint8_t)(lo | hi << 4); }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const QNibbles q{q_lds};
+		Biv *prev = A.P.pool + k.off + (k.flip ? k.n : 0), *curr = A.P.pool + k.off + (k.flip ? 0 : k.n), *mem = A.P.pool + k.off + 2 * k.n;
+		int i = k.row, n_prev = k.n_prev, nm = k.nm, mls = k.mls;
+		const uint64_t min_intv = (uint64_t)k.min_intv;
+		for (;;) {
+			if (i < -1) break;
+			const int c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
+			if (c < 0) {
+				if (n_prev > 0 && (nm == 0 || i + 1 < mls)) { if (lane == 0) { Biv x = prev[0]; x.info |= (uint64_t)(i + 1) << 32; mem[nm] = x; } ++nm; mls = i + 1; }
+				break;
+			}
+			int n_curr = 0;
+			bool carry_valid = false;
+			uint64_t carry_s = 0;
+			for (int base = 0; base < n_prev; base += 64) {
+				const int j = base + lane;
+				const bool valid = j < n_prev;
+				Biv req = Biv(), ok = Biv();
+				if (valid) { req = prev[j]; ok = extend1(A.ix, req, 1, c); }
+				const bool keep = valid && ok.s >= min_intv;
+				const unsigned long long km = __ballot(keep), fm = __ballot(valid && !keep);
+				if (n_curr == 0 && fm) { // the first interval that died, if no survivor precedes it in the row
+					const int jf = __builtin_ctzll(fm);
+					if ((km & ((1ull << jf) - 1)) == 0 && (nm == 0 || i + 1 < mls)) {
+						if (lane == jf) { Biv x = req; x.info |= (uint64_t)(i + 1) << 32; mem[nm] = x; }
+						++nm; mls = i + 1;
+					}
+				}
+				const unsigned long long below = km & ((1ull << lane) - 1);
+				const int p = below ? 63 - __builtin_clzll(below) : 0;
+				const uint64_t ps = shfl_u64(ok.s, p);
+				const uint64_t prev_s = below ? ps : carry_s;
+				const bool push = keep && (!(below || carry_valid) || ok.s != prev_s);
+				const unsigned long long pm = __ballot(push);
+				if (push) { Biv x = ok; x.info = req.info; curr[n_curr + __builtin_popcountll(pm & ((1ull << lane) - 1))] = x; }
+				n_curr += __builtin_popcountll(pm);
+				if (km) { carry_s = shfl_u64(ok.s, 63 - __builtin_clzll(km)); carry_valid = true; }
+			}
+			if (n_curr == 0) break;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the next row reads what this one wrote
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			Biv *sw = curr; curr = prev; prev = sw; n_prev = n_curr;
+			--i;
+		}
+		if (lane == 0) A.P.tasks[t].nm = nm;
+	}
+}
 
 template <class Prog, bool BY_TASK>
 __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int32_t *counter, int batch, int chunk, uint8_t *q_lds)

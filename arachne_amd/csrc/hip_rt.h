@@ -207,7 +207,8 @@ struct HipRT {
 	}
 	// seeding: persistent lanes, items handed out in chunks (hip_fm_coop.h); f is one of pipeline.h's KSeedFwd1 / KSeedFwd2 / KSeedBwd,
 	// f.scratch holds max_slots() forward lists
-	int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 16; // lanes that queue up before the slow bookkeeping runs
+	int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 48; // lanes that queue up before the slow bookkeeping runs
+	int seed_bwd_budget = getenv("ARX_SEED_BWD_BUDGET") ? atoi(getenv("ARX_SEED_BWD_BUDGET")) : 320; // extensions a lane spends on one backward sweep before handing it to a wavefront (0: never)
 	int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64; // items a wavefront reserves per atomic
 	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_)
 	{
@@ -221,22 +222,30 @@ struct HipRT {
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0};
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0, nullptr, nullptr, 0};
 		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, bpc);
 	}
 	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *counter)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0};
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0, nullptr, nullptr, 0};
 		launch_seed_kernel(nm, k_seed_fwd2, n, A, counter, bpc);
 	}
 	template <class F> void run_seed_bwd(const char *nm, int n, const F &f, int32_t *counter)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0};
+		// sweeps longer than seed_bwd_budget extensions are finished by whole wavefronts (k_seed_bwd_wave)
+		int32_t *heavy = alloc<int32_t>((size_t)n + 2);
+		memset0(heavy + n, 4);
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget};
 		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, bpc);
+		if (seed_bwd_budget > 0) {
+			Scope sc(*this, "seed_bwd_wave", n);
+			hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
+			ARX_HIP_CHECK(hipGetLastError());
+		}
 	}
 	template <class F> void run_seed_strat(const char *nm, int n, const F &f, int32_t *counter)
 	{

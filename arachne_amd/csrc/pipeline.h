@@ -19,6 +19,10 @@
 #include "dev_sw.h"
 #include "dev_regs.h"
 
+#ifndef ARX_STAT_BWD
+#define ARX_STAT_BWD(n, ext) ((void)(ext)) // the host test double can histogram the backward tasks here
+#endif
+
 namespace arx {
 
 // ---------------------------------------------------------------- kernel functors (item = work unit, slot = scratch slot)
@@ -64,7 +68,9 @@ struct KSeedBwd { // the backward sweep of task t0 + item
 		ln.start(QBytes{bases + base_off[t.read]}, t, P.pool);
 		Biv req = Biv();
 		int rc = 0;
-		while (ln.advance(&req, &rc)) ln.consume(req, extend1(ix, req, 1, rc));
+		int n_ext = 0;
+		while (ln.advance(&req, &rc)) { ln.consume(req, extend1(ix, req, 1, rc)); ++n_ext; }
+		ARX_STAT_BWD(t.n, n_ext);
 		P.tasks[t0 + item].nm = ln.nm;
 	}
 };

@@ -32,6 +32,17 @@ static void sim_stat_rescue(int n, bool ins, int clean)
 }
 struct SimStatPrinter { ~SimStatPrinter() { if (getenv("ARX_RESCUE_STATS")) fprintf(stderr, "[sim] rescue applies %ld, inserted %ld, dedup skipped %ld, mean n %.1f, mean n^2 %.1f, max n %ld; fast inserts %ld, fallbacks %ld\n", sim_rescue_calls, sim_rescue_ins, sim_rescue_skipped, sim_rescue_calls ? (double)sim_rescue_nsum / sim_rescue_calls : 0.0, sim_rescue_calls ? (double)sim_rescue_n2sum / sim_rescue_calls : 0.0, sim_rescue_nmax, sim_rescue_fast_hits, sim_rescue_fast_fallbacks); } } sim_stat_printer;
 #define ARX_STAT_RESCUE(pair, n, inserts, clean) sim_stat_rescue((n), (inserts), (clean))
+static long sim_bwd_hist_n[8], sim_bwd_hist_ext[8], sim_bwd_ext_by_n[8], sim_bwd_max_ext;
+static void sim_stat_bwd(int n, int ext)
+{
+	int a = 0; while (a < 7 && (1 << a) < n) ++a;
+	int b = 0; while (b < 7 && (16 << b) <= ext) ++b;
+	++sim_bwd_hist_n[a]; ++sim_bwd_hist_ext[b]; sim_bwd_ext_by_n[a] += ext; if (ext > sim_bwd_max_ext) sim_bwd_max_ext = ext;
+}
+struct SimBwdPrinter { ~SimBwdPrinter() { if (!getenv("ARX_BWD_STATS")) return; fprintf(stderr, "[sim] backward tasks by list length (<=1,2,4,..,128):"); for (int a = 0; a < 8; ++a) fprintf(stderr, " %ld", sim_bwd_hist_n[a]);
+	fprintf(stderr, "\n[sim]   extensions spent there:"); for (int a = 0; a < 8; ++a) fprintf(stderr, " %ld", sim_bwd_ext_by_n[a]);
+	fprintf(stderr, "\n[sim]   tasks by extensions (<16,<32,..,>=1024):"); for (int a = 0; a < 8; ++a) fprintf(stderr, " %ld", sim_bwd_hist_ext[a]); fprintf(stderr, "; max %ld\n", sim_bwd_max_ext); } } sim_bwd_printer;
+#define ARX_STAT_BWD(n, ext) sim_stat_bwd((n), (ext))
 // ARX_RESCUE_FAST=0 switches dedup_insert() off; ARX_RESCUE_CHECK=1 runs the general path next to it on a copy and aborts on any difference
 static int sim_rescue_fast_f() { const char *e = getenv("ARX_RESCUE_FAST"); return e ? atoi(e) : 1; }
 static int sim_rescue_check_f() { const char *e = getenv("ARX_RESCUE_CHECK"); return e ? atoi(e) : 0; }
