@@ -203,6 +203,12 @@ struct BwdProg { // the backward sweep of one task
 		t = A.t0 + item;
 		const SeedTask k = A.P.tasks[t];
 		if (k.n == 0) { ln.finished = true; return false; }
+		if (k.x == 0) { // nothing lies before the read: the longest forward match is the SMEM (the sweep's c < 0 case at i = -1)
+			A.P.pool[k.off + 2 * k.n] = A.P.pool[k.off];
+			A.P.tasks[t].nm = 1;
+			ln.finished = true;
+			return false;
+		}
 		ln.start(q, k, A.P.pool);
 		return true;
 	}

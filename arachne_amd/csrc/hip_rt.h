@@ -208,7 +208,7 @@ struct HipRT {
 	// seeding: persistent lanes, items handed out in chunks (hip_fm_coop.h); f is one of pipeline.h's KSeedFwd1 / KSeedFwd2 / KSeedBwd,
 	// f.scratch holds max_slots() forward lists
 	int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 48; // lanes that queue up before the slow bookkeeping runs
-	int seed_bwd_budget = getenv("ARX_SEED_BWD_BUDGET") ? atoi(getenv("ARX_SEED_BWD_BUDGET")) : 320; // extensions a lane spends on one backward sweep before handing it to a wavefront (0: never)
+	int seed_bwd_budget = getenv("ARX_SEED_BWD_BUDGET") ? atoi(getenv("ARX_SEED_BWD_BUDGET")) : 128; // extensions a lane spends on one backward sweep before handing it to a wavefront (0: never)
 	int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64; // items a wavefront reserves per atomic
 	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_)
 	{

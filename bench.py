@@ -116,9 +116,11 @@ def algorithmic_bytes(prefix, rs, n_sample):
     # the seeding kernel runs the first two passes of mem_collect_intv (SMEM search, re-seeding), the third pass has its own
     e1, e2 = c["ext_same_block"] - c["ext3_same_block"], c["ext_two_block"] - c["ext3_two_block"]
     per_read_seed = 64.0 * (e1 + 2 * e2) / reads + L / 4
+    per_read_bwd = 64.0 * (c["extb_same_block"] + 2 * c["extb_two_block"]) / reads + L / 4     # backward sweeps (re-read the bases)
+    per_read_fwd = 64.0 * ((e1 - c["extb_same_block"]) + 2 * (e2 - c["extb_two_block"])) / reads + L / 4
     per_read_strat = 64.0 * (c["ext3_same_block"] + 2 * c["ext3_two_block"]) / reads + L / 4
     per_read_locate = (64.0 * c["sa_lf_steps"] + 8.0 * c["sa_lookups"]) / reads
-    return dict(seed=per_read_seed, strat=per_read_strat, locate=per_read_locate, counters={k: v / reads for k, v in c.items() if k != "n_reads"})
+    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, counters={k: v / reads for k, v in c.items() if k != "n_reads"})
 
 
 def main():
@@ -252,27 +254,54 @@ def main():
         try:
             ab = algorithmic_bytes(prefix, rs, 10_000)
             reads_per_launch = 2.0 * rs.n_pairs / len(batches)
-            k = ktimes.get("seed")
-            ki = ktimes_iso.get("seed")
-            if k and k["calls"]:
-                avg_ms = k["ms"] / k["calls"]
-                achieved = ab["seed"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
-                # memory-side bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE pass of this command (counters
+            # The roofline kernel: the backward sweeps of bwt_smem1a, the largest of the seeding kernels (k_seed_bwd finishes its
+            # longest sweeps in k_seed_bwd_wave: the pair is one launch here; each batch launches it for the first pass and for
+            # the re-seeding pass, with half of the batch's backward bytes on average).
+            def group(kt, names):
+                ms = sum(kt[n]["ms"] for n in names if n in kt)
+                calls = kt[names[0]]["calls"] if names[0] in kt else 0
+                return ms, calls
+            ms, calls = group(ktimes, ["seed_bwd", "seed_bwd_wave"])
+            if calls:
+                launches_per_batch = 2.0
+                avg_ms = ms / calls
+                bytes_per_launch = ab["bwd"] * reads_per_launch / launches_per_batch
+                achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                # memory-side bytes of the same kernels from the committed rocprofv3 --pmc FETCH_SIZE pass of this command (counters
                 # cannot be read from inside the process); null when no such pass is committed
                 traffic, traffic_src = None, None
                 tf = os.path.join(ROOT, "profiles", "r01", "seed_traffic.json")
                 if os.path.exists(tf):
                     tj = json.load(open(tf))
-                    traffic = tj["fabric_bytes_per_read"] * reads_per_launch
-                    traffic_src = "profiles/r01/seed_traffic.json"
-                out["roofline"] = dict(kernel="seed (k_seed_dyn: SMEM search + re-seeding, bwt_smem1a/bwt_extend/bwt_2occ4)", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
-                                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_unit="bytes per launch", traffic_source=traffic_src,
-                                       algorithmic_bytes_per_read=ab["seed"], reads_per_launch=reads_per_launch, avg_launch_ms=avg_ms)
-                if ki and ki["calls"]:
-                    iso_ms = ki["ms"] / ki["calls"]
-                    iso = ab["seed"] * reads_per_launch / (iso_ms * 1e-3) / 1e9
+                    if "bwd_fabric_bytes_per_read" in tj:
+                        traffic = tj["bwd_fabric_bytes_per_read"] * reads_per_launch / launches_per_batch
+                        traffic_src = "profiles/r01/seed_traffic.json"
+                out["roofline"] = dict(kernel="seed_bwd (k_seed_bwd + k_seed_bwd_wave: backward sweeps of bwt_smem1a, bwt_extend/bwt_2occ4)", bound="hbm",
+                                       achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                                       traffic_unit="bytes per launch", traffic_source=traffic_src, algorithmic_bytes_per_read=ab["bwd"],
+                                       reads_per_launch=reads_per_launch, launches_per_batch=launches_per_batch, avg_launch_ms=avg_ms)
+                ims, icalls = group(ktimes_iso, ["seed_bwd", "seed_bwd_wave"])
+                if icalls:
+                    iso_ms = ims / icalls
+                    iso = bytes_per_launch / (iso_ms * 1e-3) / 1e9
                     out["roofline"]["isolated"] = dict(achieved=iso, frac=iso / HBM_PEAK_GBS, avg_launch_ms=iso_ms,
-                                                       note="same kernel, same inputs, launched alone after the timed region (in the timed region it co-runs with the other batches' DP kernels)")
+                                                       note="same kernels, same inputs, launched alone after the timed region (in the timed region they co-run with the other batches' DP kernels)")
+            # the whole seeding stage (forward extensions, backward sweeps, third pass, gathers) against its algorithmic bytes
+            stage = ["seed_fwd", "seed_bwd", "seed_bwd_wave", "seed_gather", "seed_strat", "seed_merge"]
+            for key, kt in (("roofline_seeding_stage", ktimes), ("roofline_seeding_stage_isolated", ktimes_iso)):
+                sms = sum(kt[n]["ms"] for n in stage if n in kt)
+                runs = kt["seed_strat"]["calls"] if "seed_strat" in kt else 0
+                if runs:
+                    tot = (ab["seed"] + ab["strat"]) * reads_per_launch
+                    ach = tot / (sms / runs * 1e-3) / 1e9
+                    out[key] = dict(kernels=stage, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                                    algorithmic_bytes_per_read=ab["seed"] + ab["strat"], ms_per_batch=sms / runs)
+            ms, calls = group(ktimes, ["seed_fwd"])
+            if calls:
+                avg_ms = ms / calls
+                ach = ab["fwd"] * reads_per_launch / 2.0 / (avg_ms * 1e-3) / 1e9
+                out["roofline_fwd"] = dict(kernel="seed_fwd (k_seed_fwd1 / k_seed_fwd2: forward extensions of bwt_smem1a)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                                           unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["fwd"], avg_launch_ms=avg_ms)
             ks3 = ktimes.get("seed_strat")
             if ks3 and ks3["calls"]:
                 avg_ms = ks3["ms"] / ks3["calls"]
