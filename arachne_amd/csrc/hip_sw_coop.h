@@ -59,11 +59,11 @@ __device__ __forceinline__ uint32_t u8_score_word(int tb)
 
 struct SwSeqs { // how the two passes read their sequences without materialising them
 	const uint8_t *mate; int l_ms;   // forward mate; the query is its reverse complement (bwamem_pair.c:134-137)
-	const uint8_t *tl;               // the target window, staged in LDS once per alignment (both passes read it)
+	const uint8_t *tl;               // the target window, staged in LDS once per alignment (both passes read it), two bases per byte
 	int q_rev, t_rev;                // second pass: the first q_rev / t_rev elements are read back to front (ksw.c:357)
 	__device__ __forceinline__ int q0(int k) const { int b = mate[l_ms - 1 - k]; return b < 4 ? 3 - b : 4; }
 	__device__ __forceinline__ int q(int k) const { return q0(k < q_rev ? q_rev - 1 - k : k); }
-	__device__ __forceinline__ int t(int i) const { return tl[i < t_rev ? t_rev - 1 - i : i]; }
+	__device__ __forceinline__ int t(int i) const { const int k = i < t_rev ? t_rev - 1 - i : i; return (tl[k >> 1] >> ((k & 1) << 2)) & 15; }
 };
 
 // one ksw_u8 pass by a 16-lane group; every lane returns the same U8Res (score2/te2 only valid in lane 0 of the group)
@@ -164,12 +164,21 @@ __device__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, 
 }
 
 // one rescue alignment per 16-lane group: forward pass, then the pass over the reversed prefixes (ksw.c:343-365)
+// the target window into LDS, two bases per byte (a per-row load of the reference base would put HBM latency on every row)
+__device__ __forceinline__ void sw_stage_target(const IndexView &ix, int64_t rb, int tlen, uint8_t *tl)
+{
+	for (int k = 2 * (__lane_id() & 15); k < tlen; k += 32) {
+		const int lo = ref_base(ix, rb + k), hi = k + 1 < tlen ? ref_base(ix, rb + k + 1) : 0;
+		tl[k >> 1] = (uint8_t)(lo | hi << 4);
+	}
+}
+
 template <int SL>
 __device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_ms, int64_t rb, int tlen, uint8_t *rowmax, uint8_t *tl, U8Res *out)
 {
 	const int xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
 	// a per-row load of the reference base would put HBM latency on the critical path of every row: fetch the window once
-	for (int k = __lane_id() & 15; k < tlen; k += 16) tl[k] = (uint8_t)ref_base(ix, rb + k);
+	sw_stage_target(ix, rb, tlen, tl);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -183,14 +192,14 @@ __device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_
 	if ((__lane_id() & 15) == 0) *out = r;
 }
 
-constexpr int SW_T_CAP = 1088; // >= PES_HIGH - PES_LOW + 2 * MAX_READ_LEN, multiple of 64
+constexpr int SW_T_CAP = 800;  // rows of a rescue window: PES_HIGH - PES_LOW + MAX_READ_LEN = 784 at most
 
 template <int SL>
 __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
                                                   const SwTask *tasks, U8Res *res, int n)
 {
 	__shared__ uint8_t rowmax_lds[4][SW_T_CAP];
-	__shared__ uint8_t target_lds[4][SW_T_CAP];
+	__shared__ uint8_t target_lds[4][SW_T_CAP / 2];
 	const int g = threadIdx.x >> 4;
 	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
 		const SwTask t = tasks[i];
@@ -294,7 +303,7 @@ __device__ void sw_u8_pass1_x2(const uint8_t *mateA, const uint8_t *mateB, int q
 	for (int i = 0; i < tmax; ++i) {
 		const bool actA = i < tlenA && !overA, actB = i < tlenB && !overB;
 		if (!actA && !actB) break;
-		const uint32_t WA = u8_score_word(actA ? tlA[i] : 0), WB = u8_score_word(actB ? tlB[i] : 0);
+		const uint32_t WA = u8_score_word(actA ? sqA.t(i) : 0), WB = u8_score_word(actB ? sqB.t(i) : 0);
 		uint32_t h = (uint32_t)g16_shift_up((int)hlast, l), f = 0, mx = 0;
 #pragma unroll
 		for (int j = 0; j < SL; ++j) {
@@ -364,7 +373,7 @@ __global__ void __launch_bounds__(64) k_sw_u8_x2(IndexView ix, const uint8_t *ba
                                                  const SwTask *tasks, U8Res *res, int n)
 {
 	__shared__ uint8_t rowmax_lds[4][2][SW_T_CAP];
-	__shared__ uint8_t target_lds[4][2][SW_T_CAP];
+	__shared__ uint8_t target_lds[4][2][SW_T_CAP / 2];
 	const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
 	const int xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
 	for (int p = blockIdx.x * 4 + g; 2 * p < n; p += gridDim.x * 4) {
@@ -382,8 +391,8 @@ __global__ void __launch_bounds__(64) k_sw_u8_x2(IndexView ix, const uint8_t *ba
 		const uint8_t *mateA = bases + base_off[rA], *mateB = bases + base_off[rB];
 		const int l_ms = lens[rA];
 		uint8_t *tlA = target_lds[g][0], *tlB = target_lds[g][1];
-		for (int k = l; k < tlenA; k += 16) tlA[k] = (uint8_t)ref_base(ix, ta.rb + k);
-		for (int k = l; k < tlenB; k += 16) tlB[k] = (uint8_t)ref_base(ix, tb.rb + k);
+		sw_stage_target(ix, ta.rb, tlenA, tlA);
+		sw_stage_target(ix, tb.rb, tlenB, tlB);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
