@@ -195,21 +195,14 @@ struct HipRT {
 	}
 	// rescue SW: 16 lanes per alignment (hip_sw_coop.h); ARX_SW_SIMPLE=1 selects the one-thread-per-alignment kernel for A/B runs
 	bool sw_simple = getenv("ARX_SW_SIMPLE") != nullptr;
-	bool sw_pairs = !(getenv("ARX_SW_PAIRS") && atoi(getenv("ARX_SW_PAIRS")) == 0); // ARX_SW_PAIRS=0: one alignment per group (A/B runs)
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); return; }
 		Scope sc(*this, nm, n);
-		if (sw_pairs) { // two alignments per 16-lane group on packed 16-bit operations
-			const int blocks = coop_blocks((n + 1) / 2);
-			if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_x2<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
-			else hipLaunchKernelGGL(k_sw_u8_x2<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
-		} else {
-			const int blocks = coop_blocks(n);
-			if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
-			else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
-		}
+		const int blocks = coop_blocks(n);
+		if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
+		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// seeding: persistent lanes, items handed out in chunks (hip_fm_coop.h); f is one of pipeline.h's KSeedFwd1 / KSeedFwd2 / KSeedBwd,

@@ -210,210 +210,6 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Two rescue alignments per 16-lane group.  Every score of ksw_u8 fits in 8 bits, so a 32-bit lane holds the same cell of
-// TWO alignments as a pair of 16-bit halves and the forward pass runs on packed 16-bit VALU operations (v_pk_add_u16,
-// v_pk_sub_u16 with clamp = _mm_subs_epu8, v_pk_max_u16, v_pk_min_u16 for the saturation at 255): one instruction stream,
-// twice the cells.  The halves never mix: the only per-half control decisions -- the lazy-F exit and the end of each
-// alignment -- are taken with half masks (a half that has left the lazy-F loop gets f = 0, which makes the remaining
-// updates no-ops for it; a half whose alignment is over no longer records maxima).  The pass over the reversed prefixes
-// (ksw.c:357) has a different query length per alignment and runs unpacked, one alignment after the other.
-// ------------------------------------------------------------------------------------------------------------------
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ uint32_t pk_rep(uint32_t v) { return v | v << 16; }
-__device__ __forceinline__ uint32_t g16_pk_max(uint32_t v)
-{
-	uint32_t t;
-	t = (uint32_t)dpp_row<DPP_ROW_ROR + 8>((int)v, (int)v); v = pk_max(v, t);
-	t = (uint32_t)dpp_row<DPP_ROW_ROR + 4>((int)v, (int)v); v = pk_max(v, t);
-	t = (uint32_t)dpp_row<DPP_ROW_ROR + 2>((int)v, (int)v); v = pk_max(v, t);
-	t = (uint32_t)dpp_row<DPP_ROW_ROR + 1>((int)v, (int)v); v = pk_max(v, t);
-	return v;
-}
-__device__ __forceinline__ uint32_t g16_or(uint32_t v)
-{
-	v |= (uint32_t)dpp_row<DPP_ROW_ROR + 8>((int)v, (int)v);
-	v |= (uint32_t)dpp_row<DPP_ROW_ROR + 4>((int)v, (int)v);
-	v |= (uint32_t)dpp_row<DPP_ROW_ROR + 2>((int)v, (int)v);
-	v |= (uint32_t)dpp_row<DPP_ROW_ROR + 1>((int)v, (int)v);
-	return v;
-}
-
-// score, te, qe, score2, te2 of one half after the packed forward pass (the tail of ksw_u8, ksw.c:203-226)
-template <int SL>
-__device__ U8Res sw_u8_finish_half(const uint32_t *HM, int shift, int slen, int gmax, int te, int rows, int minsc, const uint8_t *rowmax)
-{
-	const int l = __lane_id() & 15;
-	U8Res r;
-	r.score = gmax + 4 < 255 ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
-	if (r.score != 255) {
-		int bv = -1, bq = 0x7fffffff; // this lane's best saved value and the smallest query position holding it
-#pragma unroll
-		for (int j = 0; j < SL; ++j) {
-			if (j < slen) {
-				const int v = (int)((HM[j] >> shift) & 0xffffu), qp = j + l * slen;
-				if (v > bv) { bv = v; bq = qp; }
-			}
-		}
-		const int vmax = g16_max(bv);
-		r.qe = g16_min(bv == vmax ? bq : 0x7fffffff);
-		if (minsc < 0x10000 && l == 0) { // replay of the b[] list (ksw.c:192-200,218-226), see u8_pass() in dev_sw.h
-			const int d = r.score, low = te - d, high = te + d;
-			int bi = -1, bs = -1;
-			for (int i = 0; i < rows; ++i) {
-				const int im = rowmax[i];
-				if (im < minsc) continue;
-				if (bi < 0 || bi + 1 != i) {
-					if (bi >= 0 && (bi < low || bi > high) && bs > r.score2) { r.score2 = bs; r.te2 = bi; }
-					bi = i; bs = im;
-				} else if (bs < im) { bi = i; bs = im; }
-			}
-			if (bi >= 0 && (bi < low || bi > high) && bs > r.score2) { r.score2 = bs; r.te2 = bi; }
-		}
-	}
-	return r;
-}
-
-// forward pass of two alignments with the same query length (qlen) against their own targets; results in *ra, *rb
-template <int SL>
-__device__ void sw_u8_pass1_x2(const uint8_t *mateA, const uint8_t *mateB, int qlen, const uint8_t *tlA, const uint8_t *tlB, int tlenA, int tlenB,
-                               int xtra, uint8_t *rowmaxA, uint8_t *rowmaxB, U8Res *ra, U8Res *rb)
-{
-	const int l = __lane_id() & 15;
-	const int slen = (qlen + 15) >> 4;
-	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;
-	const SwSeqs sqA{mateA, qlen, tlA, 0, 0}, sqB{mateB, qlen, tlB, 0, 0};
-	uint32_t H0[SL], H1[SL], E[SL], HM[SL];
-	int QA[SL], QB[SL];
-#pragma unroll
-	for (int j = 0; j < SL; ++j) {
-		const int k = j + l * slen;
-		H0[j] = H1[j] = E[j] = HM[j] = 0;
-		QA[j] = 4 * ((j < slen && k < qlen) ? sqA.q(k) : 5);
-		QB[j] = 4 * ((j < slen && k < qlen) ? sqB.q(k) : 5);
-	}
-	int gmaxA = 0, gmaxB = 0, teA = -1, teB = -1, rowsA = 0, rowsB = 0;
-	bool overA = false, overB = false; // ksw_u8's early exit (score about to overflow the byte)
-	uint32_t hlast = 0;
-	const int tmax = tlenA > tlenB ? tlenA : tlenB;
-	const uint32_t C255 = pk_rep(255), C4 = pk_rep(4), C7 = pk_rep(7), C1 = pk_rep(1);
-	for (int i = 0; i < tmax; ++i) {
-		const bool actA = i < tlenA && !overA, actB = i < tlenB && !overB;
-		if (!actA && !actB) break;
-		const uint32_t WA = u8_score_word(actA ? sqA.t(i) : 0), WB = u8_score_word(actB ? sqB.t(i) : 0);
-		uint32_t h = (uint32_t)g16_shift_up((int)hlast, l), f = 0, mx = 0;
-#pragma unroll
-		for (int j = 0; j < SL; ++j) {
-			if (j < slen) {
-				const uint32_t sc = ((WA >> QA[j]) & 15u) | ((WB >> QB[j]) & 15u) << 16;
-				uint32_t t = pk_min(pk_add(h, sc), C255);      // _mm_adds_epu8
-				uint32_t hh = pk_subs(t, C4);                  // _mm_subs_epu8(h, shift)
-				hh = pk_max(pk_max(hh, E[j]), f);
-				mx = pk_max(mx, hh);
-				H1[j] = hh;
-				const uint32_t t7 = pk_subs(hh, C7);           // subs(h, oe): o+e = 7 for both gap kinds
-				E[j] = pk_max(pk_subs(E[j], C1), t7);
-				f = pk_max(pk_subs(f, C1), t7);
-				h = H0[j];
-			}
-		}
-		// lazy-F (ksw.c:177-189), each half leaving the loop on its own: `live` holds 0xffff for a half that is still in it
-		{
-			uint32_t live = (actA ? 0xffffu : 0u) | (actB ? 0xffff0000u : 0u);
-			for (int k2 = 0; k2 < 16 && live; ++k2) {
-				f = (uint32_t)g16_shift_up((int)f, l) & live;
-#pragma unroll
-				for (int j = 0; j < SL; ++j) {
-					if (j < slen && live) {
-						const uint32_t hh = pk_max(H1[j], f);
-						H1[j] = hh;
-						const uint32_t t7 = pk_subs(hh, C7);
-						f = pk_subs(f, C1);
-						const uint32_t any = g16_or(pk_subs(f, t7)); // a half is non-zero iff some lane still has f > h - oe there
-						live &= ((any & 0xffffu) ? 0xffffu : 0u) | ((any >> 16) ? 0xffff0000u : 0u);
-						f &= live;
-					}
-				}
-			}
-		}
-		const uint32_t im2 = g16_pk_max(mx);
-		const int imA = (int)(im2 & 0xffffu), imB = (int)(im2 >> 16);
-		if (actA) {
-			if (minsc < 0x10000 && l == 0) rowmaxA[i] = (uint8_t)imA;
-			++rowsA;
-			if (imA > gmaxA) {
-				gmaxA = imA; teA = i;
-#pragma unroll
-				for (int j = 0; j < SL; ++j) HM[j] = (HM[j] & 0xffff0000u) | (H1[j] & 0xffffu);
-				if (gmaxA + 4 >= 255) overA = true;
-			}
-		}
-		if (actB) {
-			if (minsc < 0x10000 && l == 0) rowmaxB[i] = (uint8_t)imB;
-			++rowsB;
-			if (imB > gmaxB) {
-				gmaxB = imB; teB = i;
-#pragma unroll
-				for (int j = 0; j < SL; ++j) HM[j] = (HM[j] & 0xffffu) | (H1[j] & 0xffff0000u);
-				if (gmaxB + 4 >= 255) overB = true;
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < SL; ++j) { H0[j] = H1[j]; if (j == slen - 1) hlast = H1[j]; }
-	}
-	*ra = sw_u8_finish_half<SL>(HM, 0, slen, gmaxA, teA, rowsA, minsc, rowmaxA);
-	*rb = sw_u8_finish_half<SL>(HM, 16, slen, gmaxB, teB, rowsB, minsc, rowmaxB);
-}
-
-template <int SL>
-__global__ void __launch_bounds__(64) k_sw_u8_x2(IndexView ix, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
-                                                 const SwTask *tasks, U8Res *res, int n)
-{
-	__shared__ uint8_t rowmax_lds[4][2][SW_T_CAP];
-	__shared__ uint8_t target_lds[4][2][SW_T_CAP / 2];
-	const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-	const int xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
-	for (int p = blockIdx.x * 4 + g; 2 * p < n; p += gridDim.x * 4) {
-		const SwTask ta = tasks[2 * p];
-		const bool two = 2 * p + 1 < n;
-		const SwTask tb = two ? tasks[2 * p + 1] : ta;
-		const int rA = 2 * ta.pair + ta.o, rB = 2 * tb.pair + tb.o;
-		const int tlenA = (int)(ta.re - ta.rb), tlenB = (int)(tb.re - tb.rb);
-		if (!two || lens[rA] != lens[rB]) { // no partner of the same query length: the one-alignment path
-			sw_u8_align_g16<SL>(ix, bases + base_off[rA], lens[rA], ta.rb, tlenA, rowmax_lds[g][0], target_lds[g][0], &res[ta.slot]);
-			if (two) sw_u8_align_g16<SL>(ix, bases + base_off[rB], lens[rB], tb.rb, tlenB, rowmax_lds[g][1], target_lds[g][1], &res[tb.slot]);
-			__builtin_amdgcn_wave_barrier();
-			continue;
-		}
-		const uint8_t *mateA = bases + base_off[rA], *mateB = bases + base_off[rB];
-		const int l_ms = lens[rA];
-		uint8_t *tlA = target_lds[g][0], *tlB = target_lds[g][1];
-		sw_stage_target(ix, ta.rb, tlenA, tlA);
-		sw_stage_target(ix, tb.rb, tlenB, tlB);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		U8Res ra, rb;
-		sw_u8_pass1_x2<SL>(mateA, mateB, l_ms, tlA, tlB, tlenA, tlenB, xtra, rowmax_lds[g][0], rowmax_lds[g][1], &ra, &rb);
-		if (!(ra.score < (xtra & 0xffff))) { // the start of each alignment: the pass over the reversed prefixes (ksw.c:343-365)
-			SwSeqs s2{mateA, l_ms, tlA, ra.qe + 1, ra.te + 1};
-			U8Res rr = sw_u8_pass_g16<SL>(s2, ra.qe + 1, tlenA, KSW_XSTOP | ra.score, rowmax_lds[g][0]);
-			if (ra.score == rr.score) { ra.tb = ra.te - rr.te; ra.qb = ra.qe - rr.qe; }
-		}
-		if (!(rb.score < (xtra & 0xffff))) {
-			SwSeqs s2{mateB, l_ms, tlB, rb.qe + 1, rb.te + 1};
-			U8Res rr = sw_u8_pass_g16<SL>(s2, rb.qe + 1, tlenB, KSW_XSTOP | rb.score, rowmax_lds[g][1]);
-			if (rb.score == rr.score) { rb.tb = rb.te - rr.te; rb.qb = rb.qe - rr.qe; }
-		}
-		if (l == 0) { res[ta.slot] = ra; res[tb.slot] = rb; }
-		__builtin_amdgcn_wave_barrier(); // the LDS rows are reused by the group's next pair
-	}
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // ext2_g16: banded extension (ksw_extend2, ksw.c:380-479) by a 16-lane group, four extensions per wavefront.
 // Column j of the reference's eh[] array lives in lane j / C, register j % C (C columns per lane, 16*C > qlen: the kernel is
 // instantiated for a few C and extensions are binned by query length).  Within a row, M(i,j) only depends on the previous
