@@ -84,23 +84,26 @@ __device__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, 
 	for (int i = 0; i < tlen; ++i) {
 		const uint32_t W = u8_score_word(sq.t(i));
 		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
+		// straight-line select code over all SL stripes: stripes past slen (a shorter query in the second pass) come last in
+		// the chain, so what they compute flows nowhere as long as they leave f and the row maximum alone
 #pragma unroll
 		for (int j = 0; j < SL; ++j) {
-			if (j < slen) {
-				int s = (int)((W >> Q4[j]) & 15u);
-				int t = h + s; t = t < 255 ? t : 255;      // _mm_adds_epu8
-				int hh = t - 4; hh = hh > 0 ? hh : 0;      // _mm_subs_epu8(h, shift)
-				hh = hh > E[j] ? hh : E[j];
-				hh = hh > f ? hh : f;
-				mx = mx > hh ? mx : hh;
-				H1[j] = hh;
-				int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;     // subs(h, oe): o+e = 7 for both gap kinds
-				int e1 = E[j] - 1; e1 = e1 > 0 ? e1 : 0;
-				E[j] = e1 > t7 ? e1 : t7;
-				int f1 = f - 1; f1 = f1 > 0 ? f1 : 0;
-				f = f1 > t7 ? f1 : t7;
-				h = H0[j];
-			}
+			const bool valid = j < slen;
+			const int s = (int)((W >> Q4[j]) & 15u);
+			int hh = h + s - 4;                           // _mm_adds_epu8 then _mm_subs_epu8(h, shift): min(h + s, 255) - 4, not below 0
+			hh = hh < 0 ? 0 : (hh > 251 ? 251 : hh);
+			hh = hh > E[j] ? hh : E[j];
+			hh = hh > f ? hh : f;
+			const int hm = valid ? hh : 0;
+			mx = mx > hm ? mx : hm;
+			H1[j] = hh;
+			int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;         // subs(h, oe): o+e = 7 for both gap kinds
+			const int e1 = E[j] - 1;                       // t7 >= 0 covers the saturation of E - 1 at 0
+			E[j] = e1 > t7 ? e1 : t7;
+			const int f1 = f - 1;
+			const int fn = f1 > t7 ? f1 : t7;
+			f = valid ? fn : f;
+			h = H0[j];
 		}
 		// lazy-F (ksw.c:177-189)
 		{
