@@ -62,6 +62,6 @@ bt = res.get("bench_plain", {})
 if isinstance(bt, dict):
     print("bench plain:", round(bt.get("value", 0)), "pairs/s; HIP-event avg seed launch", bt.get("roofline", {}).get("avg_launch_ms"))
 print("fetch calibration:", res.get("fetch_calibration"))
-for k in ("k_seed_dyn", "k_locate_dyn"):
+for k in ("k_seed_bwd", "k_seed_bwd_wave", "k_seed_fwd1", "k_seed_fwd2", "k_strat_dyn", "k_locate_dyn", "k_sw_u8_g16<10>", "k_extend_g16<4>", "k_reg2aln_nw_g16"):
     if k in pmc:
         print(k, {a: b for a, b in pmc[k].items()})
