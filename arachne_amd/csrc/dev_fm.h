@@ -187,7 +187,11 @@ struct SeedPools { // batch-wide, filled through atomic cursors; an overflow rai
 	{
 		const int t = ARX_ATOMIC_ADD(cursors + 1, 1);
 		const int off = ARX_ATOMIC_ADD(cursors, 3 * n);
-		if (t >= task_cap || (int64_t)off + 3 * n > pool_cap) { ARX_ATOMIC_OR(err, ERR_POOL_OVERFLOW); return -1; }
+		if (t >= task_cap || (int64_t)off + 3 * n > pool_cap) {
+			ARX_ATOMIC_OR(err, ERR_POOL_OVERFLOW);
+			if (t < task_cap) { SeedTask e = SeedTask(); e.read = read; e.next = -1; tasks[t] = e; } // the id is taken: leave an empty task (n = 0) the later kernels skip
+			return -1;
+		}
 		SeedTask k = SeedTask(); k.read = read; k.x = x; k.min_intv = min_intv; k.off = off; k.n = n; k.nm = 0; k.next = -1;
 		tasks[t] = k;
 		return t;

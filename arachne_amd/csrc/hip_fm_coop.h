@@ -146,7 +146,12 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 	__device__ void granted(int off, int t)
 	{
 		awaiting = false; extending = false;
-		if (t >= A.P.task_cap || (int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); over = true; return; }
+		if (t >= A.P.task_cap || (int64_t)off + 3 * ln.n > A.P.pool_cap) {
+			atomicOr(A.P.err, ERR_POOL_OVERFLOW);
+			if (t < A.P.task_cap) { SeedTask e = SeedTask(); e.read = r; e.next = -1; A.P.tasks[t] = e; } // the id is taken: leave an empty task the later kernels skip
+			over = true;
+			return;
+		}
 		SeedTask k = SeedTask(); k.read = r; k.x = x; k.min_intv = 1; k.off = off; k.n = ln.n; k.nm = 0; k.next = -1;
 		A.P.tasks[t] = k;
 		Biv *dst = A.P.pool + off;

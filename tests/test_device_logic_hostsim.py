@@ -91,3 +91,12 @@ def test_argument_errors(env):
         ref.batch(np.zeros(600, dtype=np.uint8), np.array([300, 300], dtype=np.int32))  # longer than the u8 SW allows
     with pytest.raises(api.ArachneError):
         api.Reference("/nonexistent/prefix", lib_path=SIM)
+
+
+def test_interval_pool_overflow_is_reported(env, monkeypatch):
+    """The seeding passes keep their interval lists in a batch-wide pool sized per read (ARX_SEED_POOL entries); running out of it
+    must surface as an error of arx_batch_run, never as silently missing seeds."""
+    z, ref, o = env
+    monkeypatch.setenv("ARX_SEED_POOL", "2")
+    with pytest.raises(api.ArachneError):
+        ref.batch(z["reads"][:200], z["lens"][:200]).run()

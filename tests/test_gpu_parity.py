@@ -131,3 +131,15 @@ def test_results_do_not_depend_on_batch_shape_or_schedule(built):
     act = wc["cands"][wc["cands"]["active"] == 1]
     assert len(act) == 2 * rs.n_pairs                                             # one placement per read
     ref.close()
+
+
+def test_interval_pool_overflow_is_reported(env, monkeypatch):
+    """Running out of the batch-wide interval pool of the seeding passes (ARX_SEED_POOL entries per read) must come back as an
+    error of arx_batch_run: no silent loss of seeds, no out-of-bounds access."""
+    z, ref, o = env
+    monkeypatch.setenv("ARX_SEED_POOL", "2")
+    with pytest.raises(api.ArachneError):
+        ref.batch(z["reads"][:200], z["lens"][:200]).run()
+    monkeypatch.delenv("ARX_SEED_POOL")
+    dev = ref.mem_mate_sw(z["reads"][:200], z["lens"][:200])      # the context is still usable afterwards
+    parity.check_final(dev, o.batch(z["reads"][:200], z["lens"][:200]))

@@ -16,7 +16,9 @@ prefix = bench.prepare_index("/tmp/arx_bench_cache", bench.CHR20_LEN, 0, lambda:
 g = bench.load_genome(prefix)
 rs = synth.make_reads(bench.SEED0, g, n_bc, 1000)
 ref = api.load_reference(prefix)
+t_up = time.time()
 b = ref.batch(rs.seqs, rs.lens)
+t_up = time.time() - t_up
 po = rs.pair_offsets()
 flags = np.ones(len(po) - 1, dtype=np.uint8)
 b.run(api.STAGE_ALN); b.rfa(po, flags, fetch=False)
@@ -24,6 +26,10 @@ ref.kernel_times_reset(True)
 t = time.time(); b.run(api.STAGE_ALN); t1 = time.time(); b.rfa(po, flags, fetch=False); t2 = time.time()
 kt = ref.kernel_times()
 print("wall aln %.1f ms, rfa %.1f ms" % ((t1 - t) * 1e3, (t2 - t1) * 1e3))
+t3 = time.time(); res = b.fetch(); t4 = time.time(); cands = b.rfa(po, flags); t5 = time.time()
+nbytes = sum(v.nbytes for v in res.values() if hasattr(v, "nbytes")) + cands["cands"].nbytes + cands["cand_off"].nbytes
+print("PCIe side: upload %.1f ms (%d pairs), fetch regions/alignments/CIGARs %.1f ms, rfa again + fetch candidates %.1f ms, %.1f MB of results" % (
+    t_up * 1e3, rs.n_pairs, (t4 - t3) * 1e3, (t5 - t4) * 1e3, nbytes / 1e6))
 print({k: round(v["ms"], 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])})
 if os.environ.get("ROUNDS_BRIEF"):
     sys.exit(0)
