@@ -70,7 +70,6 @@ template <class RT> struct Batch {
 	typename Pipeline<RT>::DeviceBatch db;
 	typename Pipeline<RT>::Work work;
 	BatchResult res;
-	bool downloaded = false;
 	int done_stage = 0;
 	std::vector<int32_t> lens_host;
 	RfaResult rfa;
@@ -155,7 +154,7 @@ template <class RT> struct Batch {
 			b->rt.set_timing(c->timing);                                                                                            \
 			/* stages already done are kept (run(SEED) then run(ALN) resumes); asking for a stage again restarts the batch */       \
 			if (last_stage <= b->done_stage) { b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; }        \
-			b->downloaded = false; b->rfa_marked = false;                                                                           \
+			b->rfa_marked = false;                                                                           \
 			if (b->done_stage < ARX_STAGE_SEED) {                                                                                   \
 				int rc = b->pipe.stage_seed(b->db, b->work);                                                                        \
 				if (rc == -2) { c->set_error("batch too large: seed occurrences exceed 2^30, split the batch"); return ARX_E_TOO_LARGE; } \
@@ -176,9 +175,8 @@ template <class RT> struct Batch {
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		ARX_TRY(c,                                                                                                                  \
 			b->rt.bind();                                                                                                           \
-			if (b->work.alns && !b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; }                 \
 		)                                                                                                                           \
-		c8[0] = b->db.n_reads; c8[1] = (int64_t)b->res.regs.size(); c8[2] = (int64_t)b->res.cigars.size(); c8[3] = b->res.n_occ;    \
+		c8[0] = b->db.n_reads; c8[1] = b->work.c_regs ? b->work.c_n_regs : 0; c8[2] = b->work.c_regs ? b->work.c_n_cig : 0; c8[3] = b->res.n_occ; \
 		c8[4] = b->res.ext_rounds; c8[5] = b->res.n_ext_tasks; c8[6] = b->res.rescue_rounds; c8[7] = b->res.n_sw_tasks;             \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
@@ -186,12 +184,8 @@ template <class RT> struct Batch {
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (!b->work.alns) { c->set_error("arx_batch_fetch before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }               \
-		ARX_TRY(c, b->rt.bind(); if (!b->downloaded) { b->pipe.download(b->db, b->work, b->res); b->downloaded = true; })           \
 		static_assert(sizeof(arx_reg) == sizeof(arx::Reg) && sizeof(arx_aln) == sizeof(arx::Aln), "C-ABI structs must mirror the device structs"); \
-		memcpy(reg_off, b->res.reg_off.data(), 4 * b->res.reg_off.size());                                                          \
-		memcpy(regs, b->res.regs.data(), sizeof(arx::Reg) * b->res.regs.size());                                                    \
-		memcpy(alns, b->res.alns.data(), sizeof(arx::Aln) * b->res.alns.size());                                                    \
-		memcpy(cigars, b->res.cigars.data(), 4 * b->res.cigars.size());                                                             \
+		ARX_TRY(c, b->rt.bind(); b->pipe.fetch(b->db, b->work, reg_off, (arx::Reg *)regs, (arx::Aln *)alns, cigars);)                \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_rfa(arx_ctx *h, arx_batch *bh, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int32_t penalty, \
@@ -210,10 +204,8 @@ template <class RT> struct Batch {
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (b->rfa.cand_off.empty() || !b->rfa_marked) { c->set_error("arx_batch_rfa_fetch before arx_batch_rfa"); return ARX_E_ARG; } \
-		ARX_TRY(c, b->rt.bind(); arx::RfaStage<RT>::fetch(b->pipe, b->db, b->work, b->rfa);)                                        \
 		static_assert(sizeof(arx_cand) == sizeof(arx::Cand), "C-ABI structs must mirror the device structs");                       \
-		memcpy(cand_off, b->rfa.cand_off.data(), 4 * b->rfa.cand_off.size());                                                       \
-		memcpy(cands, b->rfa.cands.data(), sizeof(arx::Cand) * b->rfa.cands.size());                                                \
+		ARX_TRY(c, b->rt.bind(); arx::RfaStage<RT>::fetch(b->pipe, b->db, b->rfa, cand_off, (arx::Cand *)cands);)                    \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_debug_intv(arx_ctx *h, arx_batch *bh, int32_t *n_intv, uint64_t *intv4)                                           \

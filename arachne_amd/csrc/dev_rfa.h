@@ -43,7 +43,7 @@ ARX_HDI int cand_pair_score2(const Cand &a, const Cand &m, int pen2) // scoreAli
 }
 
 // B2 + B3 for one read: one candidate per region (or the placeholder), statistics from the CIGAR, score filter
-ARX_DEV void cand_build_read(const IndexView &ix, int read, const Reg *regs, const Aln *alns, const uint32_t *cig, int cig_w, int g0, int n_regs, Cand *out)
+ARX_DEV void cand_build_read(const IndexView &ix, int read, const Reg *regs, const Aln *alns, const uint32_t *cig, int cig_w, int g0, int n_regs, int c0, Cand *out)
 {
 	if (n_regs == 0) { // aligner.go:1664-1676,1700-1711
 		Cand c = Cand();
@@ -61,7 +61,7 @@ ARX_DEV void cand_build_read(const IndexView &ix, int read, const Reg *regs, con
 		const int64_t cpos = rg.rb < ix.l_pac ? rg.rb - off : 2 * ix.l_pac - 1 - rg.rb - off; // InterpretAlign, gobwa.go:351-363
 		const int64_t cend = rg.re < ix.l_pac ? rg.re - off : 2 * ix.l_pac - 1 - rg.re - off;
 		int indel_len = 0;
-		c.reg = g0 + i; c.read = read; c.rid = al.rid; c.score = rg.score; c.reversed = al.is_rev; c.sum_move = 1.0; c.mol = -1;
+		c.reg = c0 + i; /* index into the dense arrays arx_batch_fetch hands out */ c.read = read; c.rid = al.rid; c.score = rg.score; c.reversed = al.is_rev; c.sum_move = 1.0; c.mol = -1;
 		const uint32_t *cg = cig + (size_t)(g0 + i) * cig_w;
 		for (int j = 0; j < al.n_cigar; ++j) {
 			const int op = cg[j] & 0xf, len = (int)(cg[j] >> 4);

@@ -359,12 +359,28 @@ struct KReg2Aln {
 	}
 };
 
+// results to dense arrays (reads in input order, a read's regions in list order): what arx_batch_fetch hands out
+struct KCompactCount {
+	const int32_t *preg_off, *n_regs, *c_off; const Aln *alns; int32_t *cig_len;
+	ARX_DEV void operator()(int r, int) const { for (int j = 0; j < n_regs[r]; ++j) cig_len[c_off[r] + j] = alns[preg_off[r] + j].n_cigar; }
+};
+struct KCompact {
+	const int32_t *preg_off, *n_regs, *c_off, *cig_off; const Reg *pregs; const Aln *alns; const uint32_t *cig; int cig_w; Reg *o_regs; Aln *o_alns; uint32_t *o_cig;
+	ARX_DEV void operator()(int r, int) const
+	{
+		for (int j = 0; j < n_regs[r]; ++j) {
+			const int g = preg_off[r] + j, d = c_off[r] + j;
+			Aln a = alns[g];
+			const uint32_t *c = cig + (size_t)g * cig_w;
+			a.cigar_off = cig_off[d];
+			for (int k = 0; k < a.n_cigar; ++k) o_cig[a.cigar_off + k] = c[k];
+			o_regs[d] = pregs[g]; o_alns[d] = a;
+		}
+	}
+};
+
 // ---------------------------------------------------------------- batch containers
-struct BatchResult { // host copies, flat (reads in input order; region rows in list order)
-	std::vector<int32_t> reg_off;   // n_reads + 1
-	std::vector<Reg> regs;
-	std::vector<Aln> alns;          // cigar_off indexes `cigars`
-	std::vector<uint32_t> cigars;
+struct BatchResult { // statistics of the run (the results themselves stay on the device until arx_batch_fetch)
 	int ext_rounds = 0, rescue_rounds = 0;
 	int64_t n_occ = 0, n_ext_tasks = 0, n_sw_tasks = 0;
 };
@@ -405,6 +421,7 @@ public:
 		Reg *regs = 0, *rtmp = 0; ExtState *est = 0; ExtTask *etask = 0; ExtRes *eres = 0; int32_t *counter = 0; uint32_t *err = 0;
 		int32_t *eh = 0; int32_t *cap = 0, *preg_off = 0, *n_regs = 0, *pidx = 0; Reg *pregs = 0, *ptmp = 0; ResState *rst = 0; SwTask *stask = 0; U8Res *sres = 0;
 		uint8_t *sw_scr = 0, *z = 0; Aln *alns = 0; uint32_t *cig = 0; int32_t *nw_list = 0;
+		int32_t *c_reg_off = 0; Reg *c_regs = 0; Aln *c_alns = 0; uint32_t *c_cig = 0; int64_t c_n_regs = 0, c_n_cig = 0; // dense results
 		int64_t T = 0, P = 0; int cig_w = 0;
 	};
 
@@ -595,7 +612,7 @@ public:
 			k.mode = 2;
 			rt.launch_small("reg2aln_nw_big", n2[1], k);
 			uint32_t e = read_err(w);
-			if (!(e & ERR_CIGAR_OVERFLOW)) return (int)e;
+			if (!(e & ERR_CIGAR_OVERFLOW)) { compact(b, w); return (int)e; }
 			if (w.cig_w >= 1024) return (int)e;
 			e &= ~ERR_CIGAR_OVERFLOW; rt.h2d(w.err, &e, 4);
 		}
@@ -615,26 +632,28 @@ public:
 	}
 
 	// copy the final region lists and alignment records to the host, compacted
-	void download(const DeviceBatch &b, Work &w, BatchResult &out)
+	// dense result arrays on the device: two scans (regions per read, CIGAR words per region) and one copy kernel
+	void compact(const DeviceBatch &b, Work &w)
 	{
-		const int R = b.n_reads; const size_t P = (size_t)w.P;
-		std::vector<int32_t> off(R + 1), n(R);
-		std::vector<Reg> pr(P + 1); std::vector<Aln> pa(P + 1); std::vector<uint32_t> cg((P + 1) * w.cig_w);
-		rt.d2h(off.data(), w.preg_off, 4 * (R + 1)); rt.d2h(n.data(), w.n_regs, 4 * R);
-		rt.d2h(pr.data(), w.pregs, sizeof(Reg) * P); rt.d2h(pa.data(), w.alns, sizeof(Aln) * P); rt.d2h(cg.data(), w.cig, 4 * P * w.cig_w);
-		out.reg_off.assign(R + 1, 0); out.regs.clear(); out.alns.clear(); out.cigars.clear();
-		for (int r = 0; r < R; ++r) {
-			out.reg_off[r] = (int32_t)out.regs.size();
-			for (int j = 0; j < n[r]; ++j) {
-				const size_t g = (size_t)off[r] + j;
-				Aln a = pa[g];
-				const uint32_t *c = cg.data() + g * w.cig_w;
-				a.cigar_off = (int32_t)out.cigars.size();
-				out.cigars.insert(out.cigars.end(), c, c + a.n_cigar);
-				out.regs.push_back(pr[g]); out.alns.push_back(a);
-			}
-		}
-		out.reg_off[R] = (int32_t)out.regs.size();
+		const int R = b.n_reads;
+		w.c_reg_off = rt.template alloc<int32_t>(R + 2);
+		w.c_n_regs = rt.exclusive_scan(w.n_regs, w.c_reg_off, R);
+		const size_t NR = (size_t)w.c_n_regs;
+		int32_t *cig_len = rt.template alloc<int32_t>(NR + 1), *cig_off = rt.template alloc<int32_t>(NR + 2);
+		KCompactCount kc{w.preg_off, w.n_regs, w.c_reg_off, w.alns, cig_len};
+		rt.launch("compact_count", R, kc);
+		w.c_n_cig = NR ? rt.exclusive_scan(cig_len, cig_off, (int)NR) : 0;
+		w.c_regs = rt.template alloc<Reg>(NR + 1); w.c_alns = rt.template alloc<Aln>(NR + 1); w.c_cig = rt.template alloc<uint32_t>((size_t)w.c_n_cig + 1);
+		KCompact kk{w.preg_off, w.n_regs, w.c_reg_off, cig_off, w.pregs, w.alns, w.cig, w.cig_w, w.c_regs, w.c_alns, w.c_cig};
+		rt.launch("compact", R, kk);
+	}
+	// straight into the caller's arrays (sized from arx_batch_counts)
+	void fetch(const DeviceBatch &b, Work &w, int32_t *reg_off, Reg *regs, Aln *alns, uint32_t *cigars)
+	{
+		rt.d2h(reg_off, w.c_reg_off, 4 * ((size_t)b.n_reads + 1));
+		rt.d2h(regs, w.c_regs, sizeof(Reg) * (size_t)w.c_n_regs);
+		rt.d2h(alns, w.c_alns, sizeof(Aln) * (size_t)w.c_n_regs);
+		rt.d2h(cigars, w.c_cig, 4 * (size_t)w.c_n_cig);
 	}
 };
 

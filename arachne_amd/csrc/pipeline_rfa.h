@@ -5,6 +5,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "pipeline.h"
 #include "dev_rfa.h"
@@ -16,8 +17,8 @@ struct KCandCount { // candidates per read: one per region, or the placeholder
 	ARX_DEV void operator()(int r, int) const { n_cand[r] = n_regs[r] ? n_regs[r] : 1; }
 };
 struct KCandBuild {
-	IndexView ix; const int32_t *preg_off, *n_regs, *cand_off; const Reg *pregs; const Aln *alns; const uint32_t *cig; int cig_w; Cand *cands;
-	ARX_DEV void operator()(int r, int) const { cand_build_read(ix, r, pregs, alns, cig, cig_w, preg_off[r], n_regs[r], cands + cand_off[r]); }
+	IndexView ix; const int32_t *preg_off, *n_regs, *c_reg_off, *cand_off; const Reg *pregs; const Aln *alns; const uint32_t *cig; int cig_w; Cand *cands;
+	ARX_DEV void operator()(int r, int) const { cand_build_read(ix, r, pregs, alns, cig, cig_w, preg_off[r], n_regs[r], c_reg_off[r], cands + cand_off[r]); }
 };
 struct KRfa { // one barcode per workgroup
 	const int32_t *cand_off; const int32_t *bc_read_off; const uint8_t *do_rfa; const int64_t *scr_off; int pen_int, n_seqs;
@@ -46,8 +47,8 @@ struct KMapq { // one read per lane: MAPQ of its active candidate; values a few 
 struct KMapqPatch { Cand *cands; const int32_t *idx, *val; ARX_DEV void operator()(int k, int) const { cands[idx[k]].mapq = val[k]; } };
 
 struct RfaResult {
-	std::vector<int32_t> cand_off; std::vector<Cand> cands; std::vector<RfaBarcodeOut> bc;
-	Cand *d_cands = nullptr; int64_t n_cands = 0; bool fetched = false; int64_t n_host_mapq = 0;
+	std::vector<int32_t> cand_off; std::vector<RfaBarcodeOut> bc;
+	Cand *d_cands = nullptr; int64_t n_cands = 0; int64_t n_host_mapq = 0;
 };
 
 template <class RT> struct RfaStage {
@@ -63,7 +64,7 @@ template <class RT> struct RfaStage {
 		rt.launch("cand_count", R, kc);
 		const int64_t NC = rt.exclusive_scan(n_cand, cand_off, R);
 		Cand *cands = rt.template alloc<Cand>((size_t)NC + 1);
-		KCandBuild kb{pipe.ix, w.preg_off, w.n_regs, cand_off, w.pregs, w.alns, w.cig, w.cig_w, cands};
+		KCandBuild kb{pipe.ix, w.preg_off, w.n_regs, w.c_reg_off, cand_off, w.pregs, w.alns, w.cig, w.cig_w, cands};
 		rt.launch("cand_build", R, kb);
 		res.cand_off.resize(R + 1);
 		rt.d2h(res.cand_off.data(), cand_off, 4 * (size_t)(R + 1));
@@ -111,7 +112,7 @@ template <class RT> struct RfaStage {
 		const int nf = pipe.read_counter(w);
 		res.n_host_mapq = nf;
 		if (nf > 0) host_mapq(rt, nf, d_flag, cands, res, bro, lmp, penalty, cen_start, cen_end, lens_host);
-		res.d_cands = cands; res.n_cands = NC; res.fetched = false; res.cands.clear();
+		res.d_cands = cands; res.n_cands = NC;
 		return 0;
 	}
 
@@ -138,23 +139,11 @@ template <class RT> struct RfaStage {
 		rt.launch("mapq_patch", nf, kp);
 	}
 
-	// candidate records to the host (arx_batch_rfa_fetch); `reg` leaves the device as a slot of the (capacity-sized)
-	// region pool, callers index the compact arrays of arx_batch_fetch
-	static void fetch(Pipeline<RT> &pipe, const typename Pipeline<RT>::DeviceBatch &b, typename Pipeline<RT>::Work &w, RfaResult &res)
+	// candidate records straight into the caller's arrays (arx_batch_rfa_fetch)
+	static void fetch(Pipeline<RT> &pipe, const typename Pipeline<RT>::DeviceBatch &b, RfaResult &res, int32_t *cand_off, Cand *cands)
 	{
-		if (res.fetched) return;
-		RT &rt = pipe.rt;
-		const int R = b.n_reads;
-		res.cands.resize((size_t)res.n_cands);
-		rt.d2h(res.cands.data(), res.d_cands, sizeof(Cand) * (size_t)res.n_cands);
-		std::vector<int32_t> po(R + 1), nr(R);
-		rt.d2h(po.data(), w.preg_off, 4 * (size_t)(R + 1)); rt.d2h(nr.data(), w.n_regs, 4 * (size_t)R);
-		int32_t compact = 0;
-		for (int r = 0; r < R; ++r) {
-			for (int i = res.cand_off[r]; i < res.cand_off[r + 1]; ++i) if (res.cands[i].reg >= 0) res.cands[i].reg = compact + (res.cands[i].reg - po[r]);
-			compact += nr[r];
-		}
-		res.fetched = true;
+		memcpy(cand_off, res.cand_off.data(), 4 * ((size_t)b.n_reads + 1));
+		pipe.rt.d2h(cands, res.d_cands, sizeof(Cand) * (size_t)res.n_cands);
 	}
 };
 
