@@ -96,7 +96,7 @@ def cpu_baseline(prefix, rs, n_sample, cores):
         kind = "port"
     out = r.batch(seqs, lens, n_threads=cores)
     secs = out["secs"]
-    return dict(value=n / secs, unit="pairs/s", cores=cores, kind=kind,
+    return dict(value=n / secs, unit="paired reads/s", cores=cores, kind=kind,
                 sample=f"first {n} pairs of the same read set, candidate generation + rescue + CIGAR for every candidate "
                        f"(gobwa.go:226-337,400-415 call sequence), {cores} OpenMP threads, {secs:.1f}s"), out
 
@@ -242,8 +242,10 @@ def main():
     if rank == 0:
         pairs_per_step = sum(r["pairs"] for r in per_rank)
         value = pairs_per_step * args.steps / dt
-        out = dict(metric="paired reads/sec through the per-barcode alignment path (seed+extend+rescue+CIGAR%s), GRCh38 chr20-size, 2x150bp" % ("" if args.no_rfa else "+RFA placement+MAPQ"),
-                   value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+        baseline = json.load(open(os.path.join(ROOT, "BASELINE.json"))) if os.path.exists(os.path.join(ROOT, "BASELINE.json")) else {}
+        out = dict(metric=baseline.get("metric", "paired reads/sec at 1/2/4/8 MI355X, GRCh38 2x150bp; CIGAR/MAPQ match vs CPU"),
+                   metric_detail="read pairs per second through the whole per-barcode path (seed + extend + rescue + CIGAR%s), results left in HBM" % ("" if args.no_rfa else " + RFA placement + MAPQ"),
+                   value=value, unit="paired reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1000.0 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u8/i16/i32 integer (max-plus DP) + u64 (FM-index)", data="synthetic",
                    config=dict(workload="BASELINE.json configs[1]: GRCh38 chr20-size genome (%d bp synthetic, planted repeats), "
