@@ -67,11 +67,12 @@ struct SwSeqs { // how the two passes read their sequences without materialising
 };
 
 // one ksw_u8 pass by a 16-lane group; every lane returns the same U8Res (score2/te2 only valid in lane 0 of the group)
-template <int SL>
-__device__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
+// FULL: the query fills all SL stripes (slen == SL, e.g. 150 bases at SL = 10), which makes every stripe test a constant
+template <int SL, bool FULL>
+__device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
 {
 	const int l = __lane_id() & 15;
-	const int slen = (qlen + 15) >> 4;
+	const int slen = FULL ? SL : (qlen + 15) >> 4;
 	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000, endsc = (xtra & KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
 	int H0[SL], H1[SL], E[SL], HM[SL], Q4[SL];
 #pragma unroll
@@ -164,6 +165,12 @@ __device__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, 
 		}
 	}
 	return r;
+}
+
+template <int SL>
+__device__ __forceinline__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
+{
+	return ((qlen + 15) >> 4) == SL ? sw_u8_pass_g16_impl<SL, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_g16_impl<SL, false>(sq, qlen, tlen, xtra, rowmax);
 }
 
 // one rescue alignment per 16-lane group: forward pass, then the pass over the reversed prefixes (ksw.c:343-365)
