@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU (run under gpurun): fresh seeded workloads of both generators, whole path + RFA against the
+CPU restatement (and the compiled reference when it travelled).  Not part of the test suite: a wider net cast once in a while."""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from arachne_amd import api, synth
+import oradrv, parity, refdrv, rfadrv, workloads
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+bad = 0
+for seed in range(100, 100 + n_seeds):
+    t = time.time()
+    if seed % 3 == 0:
+        g = synth.make_genome(seed, [1500000, 400000]); rs = synth.make_reads(seed + 1, g, 6, 500)
+    else:
+        g = workloads.nasty_genome(seed, contig_lens=(180000 + 1000 * (seed % 7), 90000, 40000), alt_contigs=seed % 3)
+        rs = workloads.nasty_reads(seed, g, n_barcodes=6, pairs_per_barcode=400)
+    d = tempfile.mkdtemp(prefix="arx_fuzz_"); fa = os.path.join(d, "g.fa")
+    g.write_fasta(fa); g.write_alt(fa + ".alt")
+    api.index_build(fa, fa)
+    ref = api.load_reference(fa, 0)
+    o = oradrv.Oracle(fa)
+    try:
+        b = ref.batch(rs.seqs, rs.lens).run()
+        dev = b.fetch()
+        ora = o.batch(rs.seqs, rs.lens, n_threads=8)
+        parity.check_final(dev, ora)
+        if refdrv.available():
+            r = refdrv.Ref(fa); parity.check_final(dev, r.batch(rs.seqs, rs.lens, n_threads=8))
+        po = rs.pair_offsets()
+        flags = [rfadrv.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(len(po) - 1)]
+        names, offs, clens, alt, l_pac = ref.contigs()
+        parity.check_rfa(b.rfa(po, flags), rfadrv.oracle_rfa(ora, rs.lens, po, flags, l_pac, offs))
+        print("seed %d ok: %d regions, %.1fs" % (seed, len(dev["regs"]), time.time() - t), flush=True)
+    except AssertionError as e:
+        bad += 1
+        print("seed %d MISMATCH: %s" % (seed, str(e)[:300]), flush=True)
+    ref.close(); o.close()
+print("fuzz done, %d mismatching seeds" % bad)
+sys.exit(1 if bad else 0)
