@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -100,6 +101,7 @@ class Batch:
         h = C.c_void_p()
         ref._check(ref.lib.arx_batch_create(ref.h, self.n_reads, bases.ctypes.data, lens.ctypes.data, C.byref(h)))
         self.h = h
+        ref._batches.add(self)
 
     def run(self, last_stage=STAGE_ALN):
         self.ref._check(self.ref.lib.arx_batch_run(self.ref.h, self.h, last_stage))
@@ -164,6 +166,7 @@ class Batch:
         if self.h:
             self.ref.lib.arx_batch_free(self.ref.h, self.h)
             self.h = None
+            self.ref._batches.discard(self)
 
     def __del__(self):
         try:
@@ -189,6 +192,7 @@ class Reference:
             self.h = None
             raise ArachneError(f"arx_open({prefix}) failed: {msg}")
         self.backend = self.lib.arx_backend().decode()
+        self._batches = weakref.WeakSet()   # batches alive on this context (arx_close frees what is left)
 
     def _check(self, rc):
         if rc != 0:
@@ -235,6 +239,9 @@ class Reference:
 
     def close(self):
         if self.h:
+            for b in list(self._batches):      # arx_close frees them: make sure no Python object frees them again
+                b.h = None
+            self._batches.clear()
             self.lib.arx_close(self.h)
             self.h = None
 

@@ -118,7 +118,17 @@ template <class RT> struct Batch {
 		*out = (arx_ctx *)c;                                                                                                        \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
-	void arx_close(arx_ctx *h) { delete (Ctx *)h; }                                                                                 \
+	void arx_close(arx_ctx *h)                                                                                                      \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		if (!c) return;                                                                                                             \
+		try {                                                                                                                       \
+			std::vector<Bat *> left;                                                                                                \
+			{ std::lock_guard<std::mutex> g(c->mu); left.assign(c->live.begin(), c->live.end()); }                                  \
+			for (Bat *b : left) delete b; /* batches the caller did not free: their handles die with the context */                 \
+			delete c;                                                                                                               \
+		} catch (...) {}                                                                                                            \
+	}                                                                                                                               \
 	const char *arx_last_error(arx_ctx *h)                                                                                          \
 	{                                                                                                                               \
 		if (!h) return g_open_error.c_str();                                                                                        \

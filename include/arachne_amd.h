@@ -57,7 +57,7 @@ int arx_index_build(const char *fasta, const char *prefix, char *msg, int32_t ms
 
 /* Loads <prefix>.{bwt,sa,pac,ann,amb,alt} (files written by `bwa index`) into HBM of `device`. */
 int arx_open(const char *prefix, int device, arx_ctx **out);
-void arx_close(arx_ctx *ctx);
+void arx_close(arx_ctx *ctx); /* also frees the context's batches that are still alive: their handles are invalid afterwards */
 const char *arx_last_error(arx_ctx *ctx);      /* ctx may be NULL after a failed arx_open */
 const char *arx_backend(void);                 /* "hip:gfx950" for the product library */
 

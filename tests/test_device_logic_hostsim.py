@@ -100,3 +100,15 @@ def test_interval_pool_overflow_is_reported(env, monkeypatch):
     monkeypatch.setenv("ARX_SEED_POOL", "2")
     with pytest.raises(api.ArachneError):
         ref.batch(z["reads"][:200], z["lens"][:200]).run()
+
+
+def test_close_frees_batches_left_alive(built):
+    """arx_close with batches still alive frees them (their handles die with the context); the binding must not free them again."""
+    z = np.load(GOLD)
+    prefix = workloads.unpack_index(z, tempfile.mkdtemp(prefix="arx_sim_close_"))
+    for _ in range(2):
+        ref = api.Reference(prefix, lib_path=SIM)
+        b = ref.batch(z["reads"][:60], z["lens"][:60]).run()
+        ref.close()
+        assert b.h is None
+        del b
