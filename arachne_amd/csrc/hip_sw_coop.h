@@ -354,6 +354,24 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 		if (last < nbeg) last = nbeg - 1;
 		beg = nbeg;
 		end = last + 2 < qlen ? last + 2 : qlen;
+		// Rows that can no longer matter.  Nothing after this row is reported unless a later row beats `max` or reaches
+		// `gscore` in the last column.  A score only grows by matches, one per remaining query column: whatever follows from
+		// eh[j].h (the diagonal predecessor of column j in the next row, stale columns included) is at most eh[j].h + (qlen - j),
+		// from eh[j].e at most eh[j].e + (qlen - 1 - j), from the row boundary at most h1 + qlen; insertions and deletions only
+		// lose.  If that bound is below both, the reference's loop would run on (up to z-drop) without changing its result:
+		// about half of the rows of a typical extension.  Checked every fourth row.
+		if ((i & 3) == 3 && m < max && gscore >= 0) {
+			int bound = beg == 0 ? h0 - (OPT_O_DEL + OPT_E_DEL * (i + 2)) + qlen : -1;
+#pragma unroll
+			for (int u = 0; u < C; ++u) {
+				const int j = c0 + u;
+				const int a = H[u] + (qlen - j), b = E[u] + (qlen - 1 - j);
+				const int x = j <= qlen ? (a > b ? a : b) : -1;
+				bound = bound > x ? bound : x;
+			}
+			bound = g16_max(bound);
+			if (bound < max && bound < gscore) break;
+		}
 	}
 	ExtRes r;
 	r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;

@@ -10,7 +10,8 @@ import oradrv, parity, refdrv, rfadrv, workloads
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 bad = 0
-for seed in range(100, 100 + n_seeds):
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+for seed in range(base, base + n_seeds):
     t = time.time()
     if seed % 3 == 0:
         g = synth.make_genome(seed, [1500000, 400000]); rs = synth.make_reads(seed + 1, g, 6, 500)
