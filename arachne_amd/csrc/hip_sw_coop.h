@@ -231,6 +231,9 @@ __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *b
 // does, which is what makes the shrinking/growing band bit-exact.  The row body is straight-line select code: every lane
 // runs the same instructions, so predication costs nothing and branches would.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef ARX_EXT_CHECK_MASK
+#define ARX_EXT_CHECK_MASK 3 // the dead-row bound of ext2_g16 is evaluated on rows with all of these bits set
+#endif
 constexpr int EXT_T_CAP = 512;
 template <int C>
 __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtTask &t, uint8_t *tl)
@@ -360,7 +363,7 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 		// from eh[j].e at most eh[j].e + (qlen - 1 - j), from the row boundary at most h1 + qlen; insertions and deletions only
 		// lose.  If that bound is below both, the reference's loop would run on (up to z-drop) without changing its result:
 		// about half of the rows of a typical extension.  Checked every fourth row.
-		if ((i & 3) == 3 && m < max && gscore >= 0) {
+		if ((i & ARX_EXT_CHECK_MASK) == ARX_EXT_CHECK_MASK && m < max && gscore >= 0) {
 			int bound = beg == 0 ? h0 - (OPT_O_DEL + OPT_E_DEL * (i + 2)) + qlen : -1;
 #pragma unroll
 			for (int u = 0; u < C; ++u) {
