@@ -143,3 +143,27 @@ def test_interval_pool_overflow_is_reported(env, monkeypatch):
     monkeypatch.delenv("ARX_SEED_POOL")
     dev = ref.mem_mate_sw(z["reads"][:200], z["lens"][:200])      # the context is still usable afterwards
     parity.check_final(dev, o.batch(z["reads"][:200], z["lens"][:200]))
+
+
+@pytest.mark.parametrize("read_len", [249, 200, 101])
+def test_other_read_lengths_take_the_wide_kernel_variants(built, read_len):
+    """Reads up to MAX_READ_LEN = 249: the 16-stripe rescue SW, the widest extension class, wide CIGAR bands."""
+    import oradrv
+    import rfadrv
+    from arachne_amd import synth
+    g = synth.make_genome(500 + read_len, [1_200_000])
+    rs = synth.make_reads(501 + read_len, g, 3, 300, read_len=read_len)
+    tmp = tempfile.mkdtemp(prefix="arx_gpu_len_")
+    prefix = os.path.join(tmp, "g.fa")
+    g.write_fasta(prefix)
+    api.index_build(prefix, prefix)
+    ref = api.load_reference(prefix, 0)
+    o = oradrv.Oracle(prefix)
+    b = ref.batch(rs.seqs, rs.lens).run()
+    ora = o.batch(rs.seqs, rs.lens, n_threads=8)
+    parity.check_final(b.fetch(), ora)
+    po = rs.pair_offsets()
+    names, offs, clens, alt, l_pac = ref.contigs()
+    parity.check_rfa(b.rfa(po, [True] * 3), rfadrv.oracle_rfa(ora, rs.lens, po, [True] * 3, l_pac, offs))
+    b.free()
+    ref.close()
