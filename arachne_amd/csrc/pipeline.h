@@ -25,6 +25,8 @@
 
 namespace arx {
 
+ARX_DEVI void raise_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); } // error bits of a batch (Pipeline::d_err)
+
 // ---------------------------------------------------------------- kernel functors (item = work unit, slot = scratch slot)
 // ---- first two passes of mem_collect_intv as forward / backward tasks (dev_fm.h).  These functors run one item per thread; the
 // HIP runtime drives the same lane programs with persistent lanes instead (hip_fm_coop.h).
@@ -33,7 +35,7 @@ struct KSeedFwd1 { // first pass, forward halves: the starts of a read chain thr
 	ARX_DEV void operator()(int r, int slot) const
 	{
 		int len = lens[r], head = -1, last = -1;
-		if (len > MAX_READ_LEN) { atomic_or_err(P.err, ERR_READ_TOO_LONG); len = 0; }
+		if (len > MAX_READ_LEN) { raise_err(P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len >= OPT_MIN_SEED_LEN) {
 			const QBytes q{bases + base_off[r]};
 			Biv *list = scratch + (size_t)slot * list_cap;
@@ -54,9 +56,7 @@ struct KSeedFwd1 { // first pass, forward halves: the starts of a read chain thr
 		}
 		first1[r] = head;
 	}
-	static ARX_DEVI void atomic_or_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); }
 };
-typedef KSeedFwd1 KSeed; // error helper used by other functors
 
 struct KSeedBwd { // the backward sweep of task t0 + item
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; int t0;
@@ -82,7 +82,7 @@ struct KSeedGather1 {
 		int ovf = 0, f2 = -1;
 		n_intv[r] = seed_gather_pass1(P, r, first1[r], bases + base_off[r], intv + (size_t)r * CAP_INTV, CAP_INTV, &ovf, &f2);
 		first2[r] = f2;
-		if (ovf) KSeed::atomic_or_err(P.err, ERR_INTV_OVERFLOW);
+		if (ovf) raise_err(P.err, ERR_INTV_OVERFLOW);
 	}
 };
 
@@ -108,7 +108,7 @@ struct KSeedGather2 {
 	{
 		int ovf = 0;
 		n_intv[r] = seed_gather_pass2(P, first2[r], intv + (size_t)r * CAP_INTV, n_intv[r], CAP_INTV, &ovf);
-		if (ovf) KSeed::atomic_or_err(P.err, ERR_INTV_OVERFLOW);
+		if (ovf) raise_err(P.err, ERR_INTV_OVERFLOW);
 	}
 };
 
@@ -138,7 +138,7 @@ struct KSeedMerge { // both interval lists of a read, sorted; the number of seed
 		int ovf = 0, occ = 0;
 		const int n = seed_merge(out, n_intv[r], strat + (size_t)r * CAP_STRAT, n_strat[r], CAP_INTV, &ovf);
 		for (int i = 0; i < n; ++i) occ += out[i].s > (uint64_t)OPT_MAX_OCC ? OPT_MAX_OCC : (int)out[i].s;
-		if (ovf) KSeed::atomic_or_err(err, ERR_INTV_OVERFLOW);
+		if (ovf) raise_err(err, ERR_INTV_OVERFLOW);
 		n_intv[r] = n; n_occ[r] = occ;
 	}
 };
@@ -178,7 +178,7 @@ struct KChain {
 		const int node0 = g0 / 3 + 4 * r, node1 = occ_off[r + 1] / 3 + 4 * (r + 1);
 		int m = chain_and_filter(ix, lens[r], intv + (size_t)r * CAP_INTV, n_intv[r], occ_seed + g0, n, next + g0, ctmp + g0,
 		                         nodes + node0, node1 - node0, iscr + 2 * (size_t)g0, cout + g0, sout + g0, g0);
-		if (m < 0) { KSeed::atomic_or_err(err, ERR_POOL_OVERFLOW); m = 0; }
+		if (m < 0) { raise_err(err, ERR_POOL_OVERFLOW); m = 0; }
 		n_chain[r] = m;
 	}
 };
@@ -347,14 +347,14 @@ struct KReg2Aln {
 				nw_list[k] = g; nw_need[k] = (int32_t)((reg2aln_z_bound(ar) + 63) >> 6);
 				return;
 			}
-			if (!reg2aln(ix, lq, bases + base_off[r], ar, (int32_t *)0, (uint8_t *)0, cig + (size_t)g * cig_w, cig_w, a)) KSeed::atomic_or_err(err, ERR_CIGAR_OVERFLOW);
+			if (!reg2aln(ix, lq, bases + base_off[r], ar, (int32_t *)0, (uint8_t *)0, cig + (size_t)g * cig_w, cig_w, a)) raise_err(err, ERR_CIGAR_OVERFLOW);
 			alns[g] = a;
 			return;
 		}
 		// worst-case traceback matrix for this region: n_col <= l_query, rows = re - rb
-		if ((int64_t)(ar.qe - ar.qb) * (ar.re - ar.rb) > z_cap) { KSeed::atomic_or_err(err, ERR_POOL_OVERFLOW); a.n_cigar = 0; a.rid = -1; alns[g] = a; return; }
+		if ((int64_t)(ar.qe - ar.qb) * (ar.re - ar.rb) > z_cap) { raise_err(err, ERR_POOL_OVERFLOW); a.n_cigar = 0; a.rid = -1; alns[g] = a; return; }
 		if (!reg2aln(ix, lq, bases + base_off[r], ar, eh + (size_t)slot * eh_words, z + (size_t)slot * z_cap, cig + (size_t)g * cig_w, cig_w, a))
-			KSeed::atomic_or_err(err, ERR_CIGAR_OVERFLOW);
+			raise_err(err, ERR_CIGAR_OVERFLOW);
 		alns[g] = a;
 	}
 };
