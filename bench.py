@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
+    ap.add_argument("--no-stagger", dest="stagger", action="store_false",
+                    help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
+                         "but three seeding stages then compete for HBM latency at once and the roofline kernel's time doubles)")
     ap.add_argument("--separate-seed", action="store_true", help="(diagnostics) seed all batches one after the other before the rest of the step")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
     ap.add_argument("--lib", default=None, help="(dry runs of this script only) alternative library exporting the C ABI")
@@ -214,17 +217,26 @@ def main():
     pool = ThreadPoolExecutor(max_workers=max(1, min(args.streams, len(batches))))
 
     def step():
-        # every batch runs start to end on its own stream: the latency-bound seeding kernel of one batch shares the chip with
-        # the VALU-bound DP kernels of the others (its HIP-event time in the timed region is therefore a co-running time; the
-        # same kernel alone is measured after the timed region and reported as roofline.isolated)
+        # every batch runs start to end on its own stream, started one after the other: a batch begins seeding when the batch
+        # before it is through with it, so that the latency-bound seeding kernels share the chip with the VALU-bound DP
+        # kernels of the earlier batches rather than with each other (their HIP-event times in the timed region are still
+        # co-running times; the same kernels alone are measured after the timed region and reported as roofline.isolated)
         if args.separate_seed:
             for b in batches:
                 b.run(api.STAGE_SEED)
-        def rest(b):
+        import threading
+        seeded = [threading.Event() for _ in batches]
+        def rest(i):
+            b = batches[i]
+            if args.stagger:     # seeding stages one after the other, each overlapping the later stages of the batches before it
+                if i > 0:
+                    seeded[i - 1].wait()
+                b.run(api.STAGE_SEED)
+                seeded[i].set()
             b.run(api.STAGE_ALN)
             if not args.no_rfa:
                 b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
-        list(pool.map(rest, batches))
+        list(pool.map(rest, range(len(batches))))
 
     for _ in range(args.warmup):
         step()
