@@ -155,7 +155,6 @@ def main():
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
                          "but three seeding stages then compete for HBM latency at once and the roofline kernel's time doubles)")
-    ap.add_argument("--separate-seed", action="store_true", help="(diagnostics) seed all batches one after the other before the rest of the step")
     ap.add_argument("--cache", default="/tmp/arx_bench_cache")
     ap.add_argument("--lib", default=None, help="(dry runs of this script only) alternative library exporting the C ABI")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for the CPU dry run of the sharding logic)")
@@ -214,37 +213,59 @@ def main():
     # every device batch has its own HIP stream; host threads drive them concurrently so that the step/DP round trips
     # of one batch overlap the kernels of the others (ctypes releases the GIL inside arx_batch_run)
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=max(1, min(args.streams, len(batches))))
+    pool = ThreadPoolExecutor(max_workers=len(batches))   # one host thread per device batch (the staggered schedule needs them all alive)
 
-    def step():
-        # every batch runs start to end on its own stream, started one after the other: a batch begins seeding when the batch
-        # before it is through with it, so that the latency-bound seeding kernels share the chip with the VALU-bound DP
-        # kernels of the earlier batches rather than with each other (their HIP-event times in the timed region are still
-        # co-running times; the same kernels alone are measured after the timed region and reported as roofline.isolated)
-        if args.separate_seed:
-            for b in batches:
-                b.run(api.STAGE_SEED)
-        import threading
-        seeded = [threading.Event() for _ in batches]
-        def rest(i):
+    import threading
+
+    def run_steps(n_steps):
+        """n_steps passes over the whole read set.  Every batch runs start to end on its own stream and host thread; the seeding
+        stages go one after the other (batch i of a step after batch i - 1, the first batch of the next step after the last of
+        this one), so that the latency-bound seeding kernels share the chip with the VALU-bound DP kernels of the batches ahead
+        of them rather than with each other.  Their HIP-event times in the timed region are still co-running times; the same
+        kernels alone are measured after the timed region and reported as roofline.isolated."""
+        nb = len(batches)
+        seeded = [[threading.Event() for _ in range(nb)] for _ in range(n_steps)]
+
+        gate = threading.Semaphore(max(1, args.streams))   # --no-stagger: at most `streams` batches in flight
+        failed = threading.Event()
+
+        def wait_for(ev):
+            while not ev.wait(0.5):
+                if failed.is_set():
+                    raise RuntimeError("another batch failed")
+
+        def worker(i):
+            try:
+                work(i)
+            except BaseException:
+                failed.set()
+                raise
+
+        def work(i):
             b = batches[i]
-            if args.stagger:     # seeding stages one after the other, each overlapping the later stages of the batches before it
+            for s_ in range(n_steps):
+                if not args.stagger:
+                    with gate:
+                        b.run(api.STAGE_ALN)
+                        if not args.no_rfa:
+                            b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
+                    continue
                 if i > 0:
-                    seeded[i - 1].wait()
+                    wait_for(seeded[s_][i - 1])
+                elif s_ > 0:
+                    wait_for(seeded[s_ - 1][nb - 1])
                 b.run(api.STAGE_SEED)
-                seeded[i].set()
-            b.run(api.STAGE_ALN)
-            if not args.no_rfa:
-                b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
-        list(pool.map(rest, range(len(batches))))
+                seeded[s_][i].set()
+                b.run(api.STAGE_ALN)
+                if not args.no_rfa:
+                    b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
+        list(pool.map(worker, range(nb)))
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     ref.kernel_times_reset(True)   # HIP events around every launch on the launch stream, resolved after the timed region
     barrier()
     t0 = time.time()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.time() - t0
     if dist is not None:
