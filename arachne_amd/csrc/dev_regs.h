@@ -615,7 +615,8 @@ ARX_DEVI int64_t reg2aln_z_bound(const Reg &ar)
 	const int min_w = iabs(l2 - l1) + 3;
 	w = w > min_w ? w : min_w;
 	const int n_col = l1 < 2 * w + 1 ? l1 : 2 * w + 1;
-	return (int64_t)n_col * l2;
+	const int stride = n_col <= 16 ? 16 : n_col <= 32 ? 32 : n_col <= 64 ? 64 : n_col <= 128 ? 128 : 256; // rows are padded to the lane tiling of the 16-lane kernel
+	return (int64_t)stride * l2;
 }
 constexpr int NW_Q_CAP = 256, NW_T_CAP = 1024; // what the 16-lane CIGAR kernel stages per region; larger regions take the one-thread path
 

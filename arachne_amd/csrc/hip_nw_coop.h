@@ -11,6 +11,7 @@
 // The matrix goes to this region's own slice of HBM (sized from its band); lane 0 walks it back and builds the CIGAR.
 #pragma once
 #include "hip_sw_coop.h"
+#include "dev_fm.h" // Q16
 
 namespace arx {
 
@@ -18,15 +19,18 @@ constexpr int DPP_ROW_SHL = 0x100;
 template <int N> __device__ __forceinline__ int g16_shift_down_n(int v, int fill) { return dpp_row<DPP_ROW_SHL + N>(fill, v); }
 
 
+constexpr int NW_ZL_BYTES = 2048; // LDS per group for the rows of the traceback matrix being walked
+__device__ __forceinline__ int g16_bcast0(int v) { return __shfl(v, __lane_id() & 48, 64); } // lane 0 of the group
+
 struct NwSeg { const uint8_t *q, *t; int qlen, tlen; }; // oriented as bwa_gen_cigar2 reads them (reverse strand: both back to front)
 
 // ksw_global2 with traceback.  Returns the score in every lane; *n_cigar (lane 0 only meaningful) may exceed cap on overflow.
 template <int CP>
-__device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint32_t *cg, int cap, int *n_cigar)
+__device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint8_t *zl, uint32_t *cg, int cap, int *n_cigar)
 {
 	const int l = __lane_id() & 15, o0 = l * CP;
 	const int qlen = sg.qlen, tlen = sg.tlen;
-	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	constexpr int stride = 16 * CP; // bytes of one row of the traceback matrix: the band (n_col <= stride columns) padded so that a lane's CP direction bytes go out as one aligned store
 	const int NEG = NW_MINUS_INF, LOW = -0x7f000000;
 	int H[CP], E[CP], M[CP], hv[CP], en[CP], pref[CP];
 #pragma unroll
@@ -56,7 +60,10 @@ __device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint32_t *cg, int cap,
 		y = g16_shift_up_n<4>(x, LOW); x = x > y ? x : y;
 		y = g16_shift_up_n<8>(x, LOW); x = x > y ? x : y;
 		const int ex = g16_shift_up_n<1>(x, LOW);
-		uint8_t *zi = z + (size_t)i * n_col;
+		uint8_t *zi = z + (size_t)i * stride;
+		uint32_t dpk[(CP + 3) / 4];
+#pragma unroll
+		for (int u = 0; u < (CP + 3) / 4; ++u) dpk[u] = 0;
 #pragma unroll
 		for (int u = 0; u < CP; ++u) {
 			const int o = o0 + u;
@@ -80,8 +87,16 @@ __device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint32_t *cg, int cap,
 				t = m - (OPT_O_INS + OPT_E_INS);
 				f -= OPT_E_INS;
 				d |= f > t ? 2 << 4 : 0;
-				zi[o] = (uint8_t)d;
+				dpk[u >> 2] |= (uint32_t)d << (8 * (u & 3));
 			} else { hv[u] = NEG; en[u] = NEG; }
+		}
+		if (o0 < nb) { // this lane's direction bytes of the row, one store
+			if (CP == 1) zi[o0] = (uint8_t)dpk[0];
+			else if (CP == 2) *(uint16_t *)(zi + o0) = (uint16_t)dpk[0];
+			else {
+#pragma unroll
+				for (int u = 0; u < (CP + 3) / 4; ++u) ((uint32_t *)(zi + o0))[u] = dpk[u];
+			}
 		}
 		if (i == tlen - 1) { // score = eh[qlen].h = H(tlen-1, qlen-1): the last active offset (w >= |tlen - qlen| + 3 puts column qlen-1 in the band)
 			int own = LOW;
@@ -105,29 +120,46 @@ __device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint32_t *cg, int cap,
 			}
 		}
 	}
-	// backtrack (ksw.c:588-603) by lane 0; ties prefer M over the gap states
+	// backtrack (ksw.c:588-603): lane 0 walks the matrix; the group copies it into LDS a block of rows at a time (a walk
+	// through HBM costs a dependent access per step), and the CIGAR run being built stays in registers until its op changes
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	if (l == 0) {
-		int n = 0, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+	{
+		constexpr int ROWS = NW_ZL_BYTES / stride;
+		int n = 0, which = 0, run_op = -1, run_len = 0;
+		int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
 		while (i >= 0 && k >= 0) {
-			which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-			if (which == 0) { n = push_cigar(cg, n, cap, 0, 1); --i; --k; }
-			else if (which == 1) { n = push_cigar(cg, n, cap, 2, 1); --i; }
-			else { n = push_cigar(cg, n, cap, 1, 1); --k; }
+			const int lo = i - ROWS + 1 > 0 ? i - ROWS + 1 : 0;
+			const int bytes = (i - lo + 1) * stride;
+			__builtin_amdgcn_wave_barrier();
+			for (int b16 = l * 16; b16 < bytes; b16 += 256) *(Q16 *)(zl + b16) = *(const Q16 *)(z + (size_t)lo * stride + b16);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			if (l == 0) {
+				while (i >= lo && k >= 0) {
+					which = zl[(i - lo) * stride + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
+					if (op == run_op) ++run_len;
+					else { if (run_op >= 0) { if (n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = op; run_len = 1; }
+					if (which == 0) { --i; --k; } else if (which == 1) --i; else --k;
+				}
+			}
+			i = g16_bcast0(i); k = g16_bcast0(k);
 		}
-		if (i >= 0) n = push_cigar(cg, n, cap, 2, i + 1);
-		if (k >= 0) n = push_cigar(cg, n, cap, 1, k + 1);
-		if (n <= cap) for (i = 0; i < n >> 1; ++i) { uint32_t xx = cg[i]; cg[i] = cg[n - 1 - i]; cg[n - 1 - i] = xx; }
-		*n_cigar = n;
+		if (l == 0) {
+			if (i >= 0) { if (run_op == 2) run_len += i + 1; else { if (run_op >= 0) { if (n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = 2; run_len = i + 1; } }
+			if (k >= 0) { if (run_op == 1) run_len += k + 1; else { if (run_op >= 0) { if (n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = 1; run_len = k + 1; } }
+			if (run_op >= 0) { if (n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; }
+			if (n <= cap) for (int a2 = 0; a2 < n >> 1; ++a2) { uint32_t xx = cg[a2]; cg[a2] = cg[n - 1 - a2]; cg[n - 1 - a2] = xx; }
+			*n_cigar = n;
+		}
 	}
 	return last_h;
 }
 
-__device__ __forceinline__ int g16_bcast0(int v) { return __shfl(v, __lane_id() & 48, 64); } // lane 0 of the group
-
 // bwa_gen_cigar2 for a region already staged in LDS (score, CIGAR, NM); every lane returns the same values
-__device__ void gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint32_t *cg, int cap, int *score, int *n_cigar, int *NM)
+__device__ void gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint8_t *zl, uint32_t *cg, int cap, int *score, int *n_cigar, int *NM)
 {
 	const int l = __lane_id() & 15;
 	const int l_query = sg.qlen, rlen = sg.tlen;
@@ -147,11 +179,11 @@ __device__ void gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint32_t *cg
 		w = w > min_w ? w : min_w;
 		const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
 		int n = 0;
-		if (n_col <= 16) sc = nw_g16<1>(sg, w, z, cg, cap, &n);
-		else if (n_col <= 32) sc = nw_g16<2>(sg, w, z, cg, cap, &n);
-		else if (n_col <= 64) sc = nw_g16<4>(sg, w, z, cg, cap, &n);
-		else if (n_col <= 128) sc = nw_g16<8>(sg, w, z, cg, cap, &n);
-		else sc = nw_g16<16>(sg, w, z, cg, cap, &n);
+		if (n_col <= 16) sc = nw_g16<1>(sg, w, z, zl, cg, cap, &n);
+		else if (n_col <= 32) sc = nw_g16<2>(sg, w, z, zl, cg, cap, &n);
+		else if (n_col <= 64) sc = nw_g16<4>(sg, w, z, zl, cg, cap, &n);
+		else if (n_col <= 128) sc = nw_g16<8>(sg, w, z, zl, cg, cap, &n);
+		else sc = nw_g16<16>(sg, w, z, zl, cg, cap, &n);
 		nc = g16_bcast0(n);
 	}
 	int nm = -1;
@@ -183,6 +215,7 @@ static __global__ void __launch_bounds__(64) k_reg2aln_nw_g16(NwArgs A, int n)
 {
 	__shared__ uint8_t lds_q[4][NW_Q_CAP];
 	__shared__ uint8_t lds_t[4][NW_T_CAP];
+	__shared__ __attribute__((aligned(16))) uint8_t lds_z[4][NW_ZL_BYTES];
 	const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
 	for (int it = blockIdx.x * 4 + grp; it < n; it += gridDim.x * 4) {
 		const int g = A.list[it];
@@ -217,7 +250,7 @@ static __global__ void __launch_bounds__(64) k_reg2aln_nw_g16(NwArgs A, int n)
 		do {
 			w2 = w2 < OPT_W << 2 ? w2 : OPT_W << 2;
 			n_cigar = 0; NM = -1;
-			if (ok) gen_cigar2_g16(sg, w2, z, cg + 1, cap - 2, &score, &n_cigar, &NM); // room for both clips
+			if (ok) gen_cigar2_g16(sg, w2, z, lds_z[grp], cg + 1, cap - 2, &score, &n_cigar, &NM); // room for both clips
 			if (n_cigar > cap - 2) { overflow = true; break; }
 			if (score == last_sc || w2 == OPT_W << 2) break;
 			last_sc = score;
