@@ -601,6 +601,20 @@ ARX_DEVI int reg2aln_w0(const Reg &ar)
 	if (w2 > OPT_W) w2 = w2 < ar.w ? w2 : ar.w;
 	return w2;
 }
+// lane tiling (columns per lane: 1, 2, 4, 8 or 16 -> class 0..4) the 16-lane CIGAR kernel takes for band w_
+ARX_DEVI int reg2aln_band_class(const Reg &ar, int w_)
+{
+	const int l1 = ar.qe - ar.qb, l2 = (int)(ar.re - ar.rb);
+	int max_gap = ((l1 + 1) >> 1) - 5;
+	max_gap = max_gap > 1 ? max_gap : 1;
+	int w = (max_gap + iabs(l2 - l1) + 1) >> 1;
+	w = w < w_ ? w : w_;
+	const int min_w = iabs(l2 - l1) + 3;
+	w = w > min_w ? w : min_w;
+	const int n_col = l1 < 2 * w + 1 ? l1 : 2 * w + 1;
+	return n_col <= 16 ? 0 : n_col <= 32 ? 1 : n_col <= 64 ? 2 : n_col <= 128 ? 3 : 4;
+}
+constexpr int NW_CLASSES = 5;
 ARX_DEVI int64_t reg2aln_z_bound(const Reg &ar)
 {
 	const int l1 = ar.qe - ar.qb, l2 = (int)(ar.re - ar.rb);

@@ -208,6 +208,7 @@ __device__ void gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint8_t *zl,
 struct NwArgs {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *preg_off, *n_regs; int n_reads; const Reg *pregs;
 	Aln *alns; uint32_t *cig; int cig_w; uint8_t *z; const int32_t *z_off; const int32_t *list; uint32_t *err;
+	const int32_t *order; // queue positions in the order they are taken (one band class per launch)
 };
 
 // mem_reg2aln for queued region list[i]; z_off in 64-byte units
@@ -217,7 +218,8 @@ static __global__ void __launch_bounds__(64) k_reg2aln_nw_g16(NwArgs A, int n)
 	__shared__ uint8_t lds_t[4][NW_T_CAP];
 	__shared__ __attribute__((aligned(16))) uint8_t lds_z[4][NW_ZL_BYTES];
 	const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-	for (int it = blockIdx.x * 4 + grp; it < n; it += gridDim.x * 4) {
+	for (int it0 = blockIdx.x * 4 + grp; it0 < n; it0 += gridDim.x * 4) {
+		const int it = A.order[it0];
 		const int g = A.list[it];
 		int lo = 0, hi = A.n_reads;
 		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.preg_off[mid] <= g) lo = mid; else hi = mid; }

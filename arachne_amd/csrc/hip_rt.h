@@ -308,15 +308,19 @@ struct HipRT {
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// CIGARs of the gapped regions: 16 lanes per region (hip_nw_coop.h); f is pipeline.h's KReg2Aln
-	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *zbuf, const int32_t *z_off)
+	template <class F> void run_reg2aln_nw(const char *nm, int n, const int32_t *n_class, const F &f, uint8_t *zbuf, const int32_t *z_off)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch_small(nm, n, f); return; }
-		Scope sc(*this, nm, n);
-		NwArgs A{f.ix, f.bases, f.base_off, f.lens, f.preg_off, f.n_regs, f.n_reads, f.pregs, f.alns, f.cig, f.cig_w, zbuf, z_off, f.nw_list, f.err};
-		int blocks = coop_blocks(n);
-		hipLaunchKernelGGL(k_reg2aln_nw_g16, dim3(blocks), dim3(64), 0, stream, A, n);
-		ARX_HIP_CHECK(hipGetLastError());
+		for (int c = 0; c < NW_CLASSES; ++c) { // one launch per band class: the four groups of a wavefront then run the same tiling
+			const int nc = n_class[c];
+			if (nc <= 0) continue;
+			Scope sc(*this, nm, nc);
+			NwArgs A{f.ix, f.bases, f.base_off, f.lens, f.preg_off, f.n_regs, f.n_reads, f.pregs, f.alns, f.cig, f.cig_w, zbuf, z_off, f.nw_list, f.err,
+			         f.class_list + (size_t)c * f.class_stride};
+			hipLaunchKernelGGL(k_reg2aln_nw_g16, dim3(coop_blocks(nc)), dim3(64), 0, stream, A, nc);
+			ARX_HIP_CHECK(hipGetLastError());
+		}
 	}
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words_per_thread)
 	{

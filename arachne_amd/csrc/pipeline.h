@@ -326,6 +326,7 @@ struct KReg2Aln {
 	Aln *alns; uint32_t *cig; int cig_w; int32_t *eh; int eh_words; uint8_t *z; int z_cap; uint32_t *err;
 	int32_t *nw_list, *nw_count; int mode; // mode 0: every region slot, gap-free ones finished inline, the rest queued; mode 1: the queued ones
 	int32_t *nw_need, *big_list; // per queued region: 64-byte units of traceback matrix; regions too long for the 16-lane kernel (nw_count[1] of them)
+	int32_t *class_list; int class_stride; // queue positions by the lane tiling of the first band (nw_count[2 + c] of class c): a wavefront's four groups then run the same code
 	ARX_DEV void operator()(int item, int slot) const
 	{
 		const int g = mode == 2 ? big_list[item] : (mode ? nw_list[item] : item);
@@ -345,6 +346,11 @@ struct KReg2Aln {
 				if (l1 > NW_Q_CAP || l2 > NW_T_CAP) { big_list[KExtStep::claim(nw_count + 1)] = g; return; }
 				const int k = KExtStep::claim(nw_count);
 				nw_list[k] = g; nw_need[k] = (int32_t)((reg2aln_z_bound(ar) + 63) >> 6);
+				int w0 = reg2aln_w0(ar); w0 = w0 < OPT_W << 2 ? w0 : OPT_W << 2;
+				const int c = reg2aln_band_class(ar, w0);
+				int at = 0;
+				for (int q = 0; q < NW_CLASSES; ++q) if (c == q) at = KExtStep::claim(nw_count + 2 + q);
+				class_list[(size_t)c * class_stride + at] = k;
 				return;
 			}
 			if (!reg2aln(ix, lq, bases + base_off[r], ar, (int32_t *)0, (uint8_t *)0, cig + (size_t)g * cig_w, cig_w, a)) raise_err(err, ERR_CIGAR_OVERFLOW);
@@ -593,21 +599,21 @@ public:
 		w.alns = rt.template alloc<Aln>(P);
 		w.nw_list = rt.template alloc<int32_t>(P);
 		int32_t *nw_need = rt.template alloc<int32_t>(P + 1), *nw_zoff = rt.template alloc<int32_t>(P + 2), *big_list = rt.template alloc<int32_t>(P);
-		int32_t *cnt2 = rt.template alloc<int32_t>(2);
+		int32_t *cnt2 = rt.template alloc<int32_t>(2 + NW_CLASSES), *class_list = rt.template alloc<int32_t>((size_t)NW_CLASSES * P + 1);
 		for (w.cig_w = 16;; w.cig_w *= 2) {
 			if (w.cig) rt.free(w.cig);
 			w.cig = rt.template alloc<uint32_t>(P * w.cig_w);
-			rt.memset0(cnt2, 8);
+			rt.memset0(cnt2, 4 * (2 + NW_CLASSES));
 			KReg2Aln k{ix, b.bases, b.base_off, b.lens, w.preg_off, w.n_regs, b.n_reads, w.pregs, w.alns, w.cig, w.cig_w, w.eh, eh_words, w.z, z_cap, w.err,
-			           w.nw_list, cnt2, 0, nw_need, big_list};
+			           w.nw_list, cnt2, 0, nw_need, big_list, class_list, (int)P};
 			rt.launch("reg2aln", (int)w.P, k);
-			int32_t n2[2];
-			rt.d2h(n2, cnt2, 8);
+			int32_t n2[2 + NW_CLASSES];
+			rt.d2h(n2, cnt2, 4 * (2 + NW_CLASSES));
 			if (n2[0] > 0) { // gapped regions: every one gets its own slice of traceback matrix, sized from its band
 				const int64_t units = rt.exclusive_scan(nw_need, nw_zoff, n2[0]);
 				uint8_t *zbuf = rt.template alloc<uint8_t>((size_t)units * 64 + 64);
 				k.mode = 1;
-				rt.run_reg2aln_nw("reg2aln_nw", n2[0], k, zbuf, nw_zoff);
+				rt.run_reg2aln_nw("reg2aln_nw", n2[0], n2 + 2, k, zbuf, nw_zoff);
 			}
 			k.mode = 2;
 			rt.launch_small("reg2aln_nw_big", n2[1], k);

@@ -123,7 +123,7 @@ struct SimRT {
 	{
 		for (int c = 0; c < EXT_CLASSES; ++c) { F fc = f; fc.tasks = f.tasks + (size_t)c * stride; launch_rows(nm, n_class[c], fc, MAX_READ_LEN + 2); }
 	}
-	template <class F> void run_reg2aln_nw(const char *nm, int n, const F &f, uint8_t *, const int32_t *) { launch(nm, n, f); }
+	template <class F> void run_reg2aln_nw(const char *nm, int n, const int32_t *, const F &f, uint8_t *, const int32_t *) { launch(nm, n, f); }
 	template <class F> void launch_rows(const char *nm, int n, const F &f, int words)
 	{
 		std::vector<uint32_t> row(words + 8);
