@@ -239,18 +239,29 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 	const int roff0 = roff[0], pen2 = 2 * pen_int; // roff holds batch-global candidate offsets, c is the barcode's slice
 	RfaView v; v.c = c; v.roff = roff; v.roff0 = roff0; v.pen2 = pen2; v.s = &s;
 	int32_t *act = s.act;
-	// R1 tagBestAlignments: per pair the best (candidate, mate candidate) over the filtered lists; exact ties: first pair wins
+	// R1 tagBestAlignments: per pair the best (candidate, mate candidate) over the filtered lists; exact ties: first pair wins.
+	// A read in a repeat has dozens of candidates and the pair loop is quadratic, so the inner loop runs per CANDIDATE (all
+	// lanes busy whatever the read), the pick per pair afterwards.
+	int32_t *v1 = s.ach, *a1 = s.num; // best mate score / mate candidate of every candidate of a first read (free until the sweeps)
+	blk.pfor(n_c, [&](int i) {
+		const int r = c[i].read - read0;
+		if ((r & 1) || !c[i].in_filtered) return;
+		int bs = 0, bm = -1;
+		for (int j = roff[r + 1] - roff0; j < roff[r + 2] - roff0; ++j) {
+			if (!c[j].in_filtered) continue;
+			const int sc = cand_pair_score2(c[i], c[j], pen2);
+			if (bm < 0 || sc > bs) { bs = sc; bm = j; }
+		}
+		v1[i] = bs; a1[i] = bm;
+	});
 	blk.pfor(n_reads / 2, [&](int pr) {
 		const int r = 2 * pr;
-		int bs = 0, ba = -1, bm = -1;
+		int bs = 0, ba = -1;
 		for (int i = roff[r] - roff0; i < roff[r + 1] - roff0; ++i) {
 			if (!c[i].in_filtered) continue;
-			for (int j = roff[r + 1] - roff0; j < roff[r + 2] - roff0; ++j) {
-				if (!c[j].in_filtered) continue;
-				const int sc = cand_pair_score2(c[i], c[j], pen2);
-				if (ba < 0 || sc > bs) { bs = sc; ba = i; bm = j; }
-			}
+			if (ba < 0 || v1[i] > bs) { bs = v1[i]; ba = i; }
 		}
+		const int bm = a1[ba];
 		c[ba].active = 1; c[bm].active = 1;
 		if (cand_is_pair(c[ba], c[bm])) { c[ba].is_proper = 1; c[bm].is_proper = 1; }
 		act[r] = ba; act[r + 1] = bm;
@@ -280,24 +291,31 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 	// markBestAlignmentForReadInMolecule: per (molecule, read) group the candidate that scores best against the mate's
 	// group in the same molecule (alone: by its own probability); ties go to the smaller position rank = index in ord,
 	// which for two candidates of one group is the order of (position, candidate index)
+	int32_t *gval = s.scv; // per candidate: its best score against the mate's group in its molecule, or its own (free until R6)
+	blk.pfor(n_c, [&](int a) { // quadratic part per candidate, as in R1
+		if (!c[a].in_filtered) return;
+		const int r = c[a].read - read0, m = c[a].mol, mlo = roff[r ^ 1] - roff0, mhi = roff[(r ^ 1) + 1] - roff0;
+		if (c[a].active) s.has_active[m] = 1;
+		int val = c[a].lap2; bool any = false;
+		for (int b = mlo; b < mhi; ++b) {
+			if (!c[b].in_filtered || c[b].mol != m) continue;
+			const int sc = cand_pair_score2(c[a], c[b], pen2);
+			if (!any || sc > val) { val = sc; any = true; }
+		}
+		gval[a] = val;
+	});
 	blk.pfor(n_reads, [&](int r) {
-		const int lo = roff[r] - roff0, hi = roff[r + 1] - roff0, mlo = roff[r ^ 1] - roff0, mhi = roff[(r ^ 1) + 1] - roff0;
+		const int lo = roff[r] - roff0, hi = roff[r + 1] - roff0;
 		for (int i = lo; i < hi; ++i) {
 			if (!c[i].in_filtered) continue;
 			const int m = c[i].mol;
-			if (c[i].active) s.has_active[m] = 1;
 			bool leader = true;
 			for (int k = lo; k < i; ++k) if (c[k].in_filtered && c[k].mol == m) { leader = false; break; }
 			if (!leader) continue;
 			int best = -1, bs = 0;
 			for (int a = i; a < hi; ++a) {
 				if (!c[a].in_filtered || c[a].mol != m) continue;
-				int val = c[a].lap2; bool any = false;
-				for (int b = mlo; b < mhi; ++b) {
-					if (!c[b].in_filtered || c[b].mol != m) continue;
-					const int sc = cand_pair_score2(c[a], c[b], pen2);
-					if (!any || sc > val) { val = sc; any = true; }
-				}
+				const int val = gval[a];
 				const bool before = best >= 0 && (c[a].pos < c[best].pos); // a > best in index, so it ranks first only on a smaller position
 				if (best < 0 || val > bs || (val == bs && before)) { bs = val; best = a; }
 			}
