@@ -7,7 +7,7 @@
 
 namespace arx {
 
-constexpr int BLOCK_LANES = 256;
+constexpr int BLOCK_LANES = 256, SORT_LDS = 4096;
 
 struct HipBlock {
 	int tid;
@@ -48,8 +48,19 @@ struct HipBlock {
 		__syncthreads();
 		return total;
 	}
-	// ascending bitonic sort of P = 2^k (key, value) pairs by (key, (uint32)value)
+	// ascending bitonic sort of P = 2^k (key, value) pairs by (key, (uint32)value); up to SORT_LDS pairs are sorted in LDS
+	uint64_t *sk; int32_t *sv; // SORT_LDS entries of LDS each
 	__device__ void sort_kv(uint64_t *k, int32_t *v, int P)
+	{
+		if (P <= SORT_LDS) {
+			for (int t = tid; t < P; t += BLOCK_LANES) { sk[t] = k[t]; sv[t] = v[t]; }
+			__syncthreads();
+			sort_kv_in(sk, sv, P);
+			for (int t = tid; t < P; t += BLOCK_LANES) { k[t] = sk[t]; v[t] = sv[t]; }
+			__syncthreads();
+		} else sort_kv_in(k, v, P);
+	}
+	__device__ void sort_kv_in(uint64_t *k, int32_t *v, int P)
 	{
 		for (int size = 2; size <= P; size <<= 1)
 			for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -86,7 +97,9 @@ template <class F> __global__ __launch_bounds__(BLOCK_LANES) void k_block_items(
 {
 	__shared__ uint64_t l64[BLOCK_LANES];
 	__shared__ int32_t l32[BLOCK_LANES + 1];
-	HipBlock blk{(int)threadIdx.x, l64, l32};
+	__shared__ uint64_t sk[SORT_LDS];
+	__shared__ int32_t sv[SORT_LDS];
+	HipBlock blk{(int)threadIdx.x, l64, l32, sk, sv};
 	for (int b = blockIdx.x; b < n; b += gridDim.x) { f(b, blk); __syncthreads(); }
 }
 
