@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
+    ap.add_argument("--depth", type=int, default=1, help="batch handles per chunk of the read set (steps in flight)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
                          "but three seeding stages then compete for HBM latency at once and the roofline kernel's time doubles)")
@@ -197,23 +198,29 @@ def main():
         assert ref.backend == "hip:gfx950", ref.backend
     # whole barcodes per device batch; reads go to HBM before the clock starts
     po = rs.pair_offsets()
-    batches, start = [], 0
-    while start < len(po) - 1:
-        end = start + 1
-        while end < len(po) - 1 and po[end + 1] - po[start] <= args.chunk_pairs:
-            end += 1
-        p0, p1 = int(po[start]), int(po[end])
-        b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1])
-        b.bc_pair_off = (po[start:end + 1] - po[start]).astype(np.int64)
-        b.do_rfa = np.array([api.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(start, end)], dtype=np.uint8)
-        batches.append(b)
-        start = end
-    log(f"rank {rank}: {len(batches)} device batches uploaded")
+    # `depth` handles per chunk of the read set: step s works on set s % depth, so that the first batches of a step can start while
+    # the last ones of the step before are still in their late stages (each handle has its own stream and work memory)
+    sets = []
+    for _d in range(max(1, args.depth)):
+        bs, start = [], 0
+        while start < len(po) - 1:
+            end = start + 1
+            while end < len(po) - 1 and po[end + 1] - po[start] <= args.chunk_pairs:
+                end += 1
+            p0, p1 = int(po[start]), int(po[end])
+            b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1])
+            b.bc_pair_off = (po[start:end + 1] - po[start]).astype(np.int64)
+            b.do_rfa = np.array([api.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(start, end)], dtype=np.uint8)
+            bs.append(b)
+            start = end
+        sets.append(bs)
+    batches = sets[0]
+    log(f"rank {rank}: {len(batches)} device batches uploaded (x{len(sets)} handles)")
 
     # every device batch has its own HIP stream; host threads drive them concurrently so that the step/DP round trips
     # of one batch overlap the kernels of the others (ctypes releases the GIL inside arx_batch_run)
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=len(batches))   # one host thread per device batch (the staggered schedule needs them all alive)
+    pool = ThreadPoolExecutor(max_workers=len(batches) * len(sets))   # one host thread per batch handle (the staggered schedule needs them all alive)
 
     import threading
 
@@ -234,16 +241,16 @@ def main():
                 if failed.is_set():
                     raise RuntimeError("another batch failed")
 
-        def worker(i):
+        def worker(di):
             try:
-                work(i)
+                work(di // nb, di % nb)
             except BaseException:
                 failed.set()
                 raise
 
-        def work(i):
-            b = batches[i]
-            for s_ in range(n_steps):
+        def work(d, i):
+            b = sets[d][i]
+            for s_ in range(d, n_steps, len(sets)):
                 if not args.stagger:
                     with gate:
                         b.run(api.STAGE_ALN)
@@ -259,7 +266,7 @@ def main():
                 b.run(api.STAGE_ALN)
                 if not args.no_rfa:
                     b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
-        list(pool.map(worker, range(nb)))
+        list(pool.map(worker, range(nb * len(sets))))
 
     run_steps(args.warmup)
     ref.kernel_times_reset(True)   # HIP events around every launch on the launch stream, resolved after the timed region
@@ -391,8 +398,9 @@ def main():
             except Exception as e:
                 log("cpu baseline skipped:", repr(e))
         print(json.dumps(out), flush=True)
-    for b in batches:
-        b.free()
+    for bs in sets:
+        for b in bs:
+            b.free()
     ref.close()
     if dist is not None:
         dist.barrier()
