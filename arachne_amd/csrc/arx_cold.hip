@@ -6,7 +6,9 @@
 #include "pipeline.h"
 
 namespace arx {
-template <class F> void HipRT::launch_cold(const char *nm, int n, const F &f) { launch_cold_impl(nm, n, f); }
+template <class F> struct ColdUsesSlots { static const bool value = true; };
+template <> struct ColdUsesSlots<KRescueStep> { static const bool value = false; }; // no per-slot scratch: may take one item per lane
+template <class F> void HipRT::launch_cold(const char *nm, int n, const F &f) { launch_cold_impl(nm, n, f, !ColdUsesSlots<F>::value); }
 template void HipRT::launch_cold<KDedup>(const char *, int, const KDedup &);
 template void HipRT::launch_cold<KRescueStep>(const char *, int, const KRescueStep &);
 } // namespace arx

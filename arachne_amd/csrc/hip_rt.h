@@ -157,6 +157,17 @@ struct HipRT {
 	std::map<std::string, KernelTimer> &timers() { resolve_timers(); return tm; }
 	void timers_reset(bool enable) { resolve_timers(); tm.clear(); timing = enable; }
 
+	// for functors that use no per-slot scratch: one item per lane, as many blocks as that takes -- the hardware hands blocks to CUs
+	// as they free up, which balances kernels whose items differ a lot in cost better than a fixed grid-stride assignment
+	bool wide_ok = !(getenv("ARX_WIDE") && atoi(getenv("ARX_WIDE")) == 0);
+	template <class F> void launch_wide(const char *nm, int n, const F &f)
+	{
+		if (n <= 0) return;
+		if (!wide_ok) { launch(nm, n, f); return; }
+		Scope sc(*this, nm, n);
+		hipLaunchKernelGGL(k_items<F>, dim3((n + 63) / 64), dim3(64), 0, stream, f, n);
+		ARX_HIP_CHECK(hipGetLastError());
+	}
 	template <class F> void launch(const char *nm, int n, const F &f)
 	{
 		if (n <= 0) return;
@@ -168,11 +179,11 @@ struct HipRT {
 	// "cold" kernels (list bookkeeping: dedup, rescue_step) are instantiated in arx_cold.hip, which is compiled at -O1:
 	// hipcc 7.2 at -O2/-O3 emits a dedup kernel that never terminates on gfx950 ("toolchain notes").
 	template <class F> void launch_cold(const char *nm, int n, const F &f);
-	template <class F> void launch_cold_impl(const char *nm, int n, const F &f)
+	template <class F> void launch_cold_impl(const char *nm, int n, const F &f, bool wide = false)
 	{
 		if (n <= 0) return;
 		Scope sc(*this, nm, n);
-		int blocks = (n + 63) / 64; if (blocks > max_blocks()) blocks = max_blocks();
+		int blocks = (n + 63) / 64; if (!(wide && wide_ok) && blocks > max_blocks()) blocks = max_blocks();
 		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}

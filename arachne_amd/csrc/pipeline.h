@@ -470,7 +470,7 @@ public:
 		KSeedBwd kb{ix, b.bases, b.base_off, b.lens, P, 0};
 		rt.run_seed_bwd("seed_bwd", n1, kb, w.counter);
 		KSeedGather1 kg1{b.bases, b.base_off, P, first1, w.intv, w.n_intv, first2};
-		rt.launch("seed_gather", R, kg1);
+		rt.launch_wide("seed_gather", R, kg1);
 		rt.d2h(cur, P.cursors, 8);
 		const int n2 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
 		KSeedFwd2 kf2{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, n1};
@@ -478,18 +478,18 @@ public:
 		kb.t0 = n1;
 		rt.run_seed_bwd("seed_bwd", n2 - n1, kb, w.counter);
 		KSeedGather2 kg2{P, first2, w.intv, w.n_intv};
-		rt.launch("seed_gather", R, kg2);
+		rt.launch_wide("seed_gather", R, kg2);
 		KSeedStrat k3{ix, b.bases, b.base_off, b.lens, strat, n_strat};
 		rt.run_seed_strat("seed_strat", R, k3, w.counter);
 		KSeedMerge km{w.intv, w.n_intv, strat, n_strat, w.n_occ, w.err};
-		rt.launch("seed_merge", R, km);
+		rt.launch_wide("seed_merge", R, km);
 		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R);
 		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
 		w.T = total;
 		w.occ_seed = rt.template alloc<Seed>(w.T + 1);
 		if (w.T) {
 			KOccFill kf{w.intv, w.n_intv, w.occ_off, w.occ_seed};
-			rt.launch("occ_fill", R, kf);
+			rt.launch_wide("occ_fill", R, kf);
 			KLocate kl{ix, w.occ_seed};
 			rt.run_locate("locate", (int)w.T, kl, w.counter);
 		}
@@ -504,7 +504,7 @@ public:
 		w.nodes = rt.template alloc<BtNode>(T / 3 + 4 * (size_t)R + 8); w.iscr = rt.template alloc<int32_t>(2 * T); w.sout = rt.template alloc<Seed>(T);
 		w.n_chain = rt.template alloc<int32_t>(R + 1);
 		KChain k{ix, b.lens, w.intv, w.n_intv, w.occ_off, w.occ_seed, w.next, w.ctmp, w.nodes, w.iscr, w.cout, w.sout, w.n_chain, w.err};
-		rt.launch("chain", R, k);
+		rt.launch_wide("chain", R, k);
 	}
 
 	// ---- stage 4: extension rounds, then de-duplication -> core regions of every read
@@ -526,13 +526,13 @@ public:
 		int32_t *n_ext = rt.template alloc<int32_t>(R + 1);
 		Reg *pool = w.rtmp; // the chains' regions while they are extended; gathered into w.regs in chain order afterwards
 		KExtInit ki{ix, b.lens, w.occ_off, w.n_chain, chain_off, w.cout, w.sout, w.srt, w.est, chain_read};
-		rt.launch("ext_init", R, ki);
+		rt.launch_wide("ext_init", R, ki);
 		int n_act = NCH;
 		for (int round = 2; n_act > 0; ++round) {
 			rt.memset0(ecnt, 4 * (EXT_CLASSES + 1));
 			KExtStep ks{ix, b.base_off, b.lens, w.occ_off, chain_off, chain_read, w.cout, w.sout, w.srt, pool, w.est, w.eres, w.etask, ecnt, round,
 			            NCH + 1, round == 2 ? nullptr : act[round & 1], act[(round + 1) & 1]};
-			rt.launch("ext_step", n_act, ks);
+			rt.launch_wide("ext_step", n_act, ks);
 			int32_t cnt[EXT_CLASSES + 1];
 			rt.d2h(cnt, ecnt, 4 * (EXT_CLASSES + 1));
 			n_act = cnt[EXT_CLASSES];
@@ -546,7 +546,7 @@ public:
 			rt.run_extend("extend", cnt, NCH + 1, ke);
 		}
 		KExtGather kg{w.occ_off, w.n_chain, chain_off, w.cout, w.est, pool, w.regs, n_ext};
-		rt.launch("ext_gather", R, kg);
+		rt.launch_wide("ext_gather", R, kg);
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
 		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core};
 		rt.launch_cold("dedup", R, kd);
@@ -558,7 +558,7 @@ public:
 		const int R = b.n_reads, NP = R / 2, slots = rt.max_slots();
 		w.cap = rt.template alloc<int32_t>(R + 1); w.preg_off = rt.template alloc<int32_t>(R + 2); w.n_regs = rt.template alloc<int32_t>(R + 1);
 		KPairCap kc{w.n_core, w.cap};
-		rt.launch("pair_cap", NP, kc);
+		rt.launch_wide("pair_cap", NP, kc);
 		w.P = rt.exclusive_scan(w.cap, w.preg_off, R);
 		const size_t P = (size_t)w.P + 1;
 		w.pregs = rt.template alloc<Reg>(P); w.ptmp = rt.template alloc<Reg>(P); w.pidx = rt.template alloc<int32_t>(P);
@@ -569,7 +569,7 @@ public:
 		const int q_cap = (b.max_len + 15) & ~15, t_cap = (PES_HIGH - PES_LOW + 2 * b.max_len + 31) & ~15;
 		w.sw_scr = rt.template alloc<uint8_t>((size_t)slots * (q_cap + 2 * t_cap));
 		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst};
-		rt.launch("pair_init", NP, ki);
+		rt.launch_wide("pair_init", NP, ki);
 		for (int round = 0;; ++round) {
 			rt.memset0(w.counter, 4);
 			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter, n_slots, getenv("ARX_RESCUE_NO_AHEAD") ? 1 : 0, (int32_t)(2 * w.P)};
@@ -647,11 +647,11 @@ public:
 		const size_t NR = (size_t)w.c_n_regs;
 		int32_t *cig_len = rt.template alloc<int32_t>(NR + 1), *cig_off = rt.template alloc<int32_t>(NR + 2);
 		KCompactCount kc{w.preg_off, w.n_regs, w.c_reg_off, w.alns, cig_len};
-		rt.launch("compact_count", R, kc);
+		rt.launch_wide("compact_count", R, kc);
 		w.c_n_cig = NR ? rt.exclusive_scan(cig_len, cig_off, (int)NR) : 0;
 		w.c_regs = rt.template alloc<Reg>(NR + 1); w.c_alns = rt.template alloc<Aln>(NR + 1); w.c_cig = rt.template alloc<uint32_t>((size_t)w.c_n_cig + 1);
 		KCompact kk{w.preg_off, w.n_regs, w.c_reg_off, cig_off, w.pregs, w.alns, w.cig, w.cig_w, w.c_regs, w.c_alns, w.c_cig};
-		rt.launch("compact", R, kk);
+		rt.launch_wide("compact", R, kk);
 	}
 	// straight into the caller's arrays (sized from arx_batch_counts)
 	void fetch(const DeviceBatch &b, Work &w, int32_t *reg_off, Reg *regs, Aln *alns, uint32_t *cigars)

@@ -61,11 +61,11 @@ template <class RT> struct RfaStage {
 		const int R = b.n_reads;
 		int32_t *n_cand = rt.template alloc<int32_t>(R + 1), *cand_off = rt.template alloc<int32_t>(R + 2);
 		KCandCount kc{w.n_regs, n_cand};
-		rt.launch("cand_count", R, kc);
+		rt.launch_wide("cand_count", R, kc);
 		const int64_t NC = rt.exclusive_scan(n_cand, cand_off, R);
 		Cand *cands = rt.template alloc<Cand>((size_t)NC + 1);
 		KCandBuild kb{pipe.ix, w.preg_off, w.n_regs, w.c_reg_off, cand_off, w.pregs, w.alns, w.cig, w.cig_w, cands};
-		rt.launch("cand_build", R, kb);
+		rt.launch_wide("cand_build", R, kb);
 		res.cand_off.resize(R + 1);
 		rt.d2h(res.cand_off.data(), cand_off, 4 * (size_t)(R + 1));
 		// per-barcode scratch offsets
@@ -108,7 +108,7 @@ template <class RT> struct RfaStage {
 		const char *ge = getenv("ARX_MAPQ_GUARD"); // tests widen the guard to push every read through the host path
 		const double guard = ge ? atof(ge) : RFA_MAPQ_GUARD;
 		KMapq km{cands, cand_off, b.lens, d_bro, n_barcodes, d_lmp, penalty, d_cs, d_ce, guard, d_flag, w.counter};
-		rt.launch("mapq", R, km);
+		rt.launch_wide("mapq", R, km);
 		const int nf = pipe.read_counter(w);
 		res.n_host_mapq = nf;
 		if (nf > 0) host_mapq(rt, nf, d_flag, cands, res, bro, lmp, penalty, cen_start, cen_end, lens_host);
@@ -136,7 +136,7 @@ template <class RT> struct RfaStage {
 		int32_t *d_i = rt.template alloc<int32_t>(nf), *d_v = rt.template alloc<int32_t>(nf);
 		rt.h2d(d_i, pidx.data(), 4 * (size_t)nf); rt.h2d(d_v, pval.data(), 4 * (size_t)nf);
 		KMapqPatch kp{cands, d_i, d_v};
-		rt.launch("mapq_patch", nf, kp);
+		rt.launch_wide("mapq_patch", nf, kp);
 	}
 
 	// candidate records straight into the caller's arrays (arx_batch_rfa_fetch)

@@ -111,6 +111,7 @@ struct SimRT {
 	void timers_reset(bool) { tm.clear(); }
 	template <class F> void launch(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; for (int i = 0; i < n; ++i) f(i, 0); }
 	template <class F> void launch_small(const char *nm, int n, const F &f) { launch(nm, n, f); }
+	template <class F> void launch_wide(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void launch_block(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; SimBlock blk; for (int i = 0; i < n; ++i) f(i, blk); }
 	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
