@@ -91,6 +91,20 @@ def test_argument_errors(env):
         ref.batch(np.zeros(600, dtype=np.uint8), np.array([300, 300], dtype=np.int32))  # longer than the u8 SW allows
     with pytest.raises(api.ArachneError):
         api.Reference("/nonexistent/prefix", lib_path=SIM)
+    b = ref.batch(z["reads"][:40], z["lens"][:40])
+    with pytest.raises(api.ArachneError):
+        b.fetch()                                         # results before arx_batch_run
+    with pytest.raises(api.ArachneError):
+        b.rfa([0, 20], [True])                            # placement before the alignment stage
+    b.run()
+    with pytest.raises(api.ArachneError):
+        b.rfa([0, 10], [True])                            # barcode offsets must cover the batch
+    with pytest.raises(api.ArachneError):
+        b.rfa([5, 20], [True])
+    assert len(b.rfa([0, 20], [False])["cands"]) >= 40    # still usable afterwards
+    b.free()
+    with pytest.raises(api.ArachneError):
+        ref.batch(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32))   # an empty batch is refused, not crashed on
 
 
 def test_interval_pool_overflow_is_reported(env, monkeypatch):
