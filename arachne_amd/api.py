@@ -35,6 +35,9 @@ CAND_DTYPE = np.dtype([("pos", "<i8"), ("aend", "<i8"), ("sum_move", "<f8"), ("r
 CAP_INTV = 256
 STAGE_SEED, STAGE_CHAIN, STAGE_EXTEND, STAGE_RESCUE, STAGE_ALN = 1, 2, 3, 4, 5
 
+POST_DTYPE = np.dtype([("qb", "<i4"), ("qe", "<i4"), ("matches", "<i4"), ("n_mm", "<i4"), ("mm_off", "<i4"), ("duplicate", "<i4")])
+SPLIT_DTYPE = np.dtype([("split", "<i4"), ("mapq", "<i4"), ("is_proper", "<i4"), ("n_split_cand", "<i4"), ("order_pinned", "<i4"),
+                        ("second_best2", "<i4"), ("score2", "<i4"), ("pad", "<i4")])
 _NT4 = np.full(256, 4, dtype=np.uint8)
 for _i, _c in enumerate("ACGT"):
     _NT4[ord(_c)] = _i
@@ -74,6 +77,8 @@ def _load(path):
     lib.arx_batch_debug_core.argtypes = [vp, vp, vp, vp]
     lib.arx_batch_rfa.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.arx_batch_rfa_fetch.argtypes = [vp, vp, vp, vp]
+    lib.arx_batch_post.argtypes = [vp, vp, vp]
+    lib.arx_batch_post_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     return lib
@@ -98,6 +103,7 @@ class Batch:
             raise ArachneError("bases do not match lens")
         self.n_reads = len(lens)
         self._keep = (bases, lens)
+        self._n_cands = 0
         h = C.c_void_p()
         ref._check(ref.lib.arx_batch_create(ref.h, self.n_reads, bases.ctypes.data, lens.ctypes.data, C.byref(h)))
         self.h = h
@@ -155,12 +161,27 @@ class Batch:
         n = C.c_int64()
         self.ref._check(self.ref.lib.arx_batch_rfa(self.ref.h, self.h, len(bco) - 1, bco.ctypes.data, flags.ctypes.data, int(penalty),
                                                    cs.ctypes.data if cs is not None else None, ce.ctypes.data if ce is not None else None, C.byref(n)))
+        self._n_cands = int(n.value)
         if not fetch:
             return int(n.value)
         off = np.zeros(self.n_reads + 1, dtype=np.int32)
         cands = np.zeros(n.value, dtype=CAND_DTYPE)
         self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, off.ctypes.data, cands.ctypes.data))
         return dict(cand_off=off, cands=cands)
+
+    def post(self, fetch=True):
+        """The passes between placement and the BAM records (needs rfa()): CIGAR walk with mismatch locations, markDuplicates,
+        CheckSplitReads.  -> dict(post, split, mm_ref, mm_read), see arx_cand_post / arx_split."""
+        n = C.c_int64()
+        self.ref._check(self.ref.lib.arx_batch_post(self.ref.h, self.h, C.byref(n)))
+        if not fetch:
+            return int(n.value)
+        post = np.zeros(self._n_cands, dtype=POST_DTYPE)
+        split = np.zeros(self.n_reads, dtype=SPLIT_DTYPE)
+        mm_ref = np.zeros(max(n.value, 1), dtype=np.int32)
+        mm_read = np.zeros(max(n.value, 1), dtype=np.int32)
+        self.ref._check(self.ref.lib.arx_batch_post_fetch(self.ref.h, self.h, post.ctypes.data, split.ctypes.data, mm_ref.ctypes.data, mm_read.ctypes.data))
+        return dict(post=post, split=split, mm_ref=mm_ref[:n.value], mm_read=mm_read[:n.value])
 
     def free(self):
         if self.h:

@@ -15,6 +15,7 @@
 #include "index_build.h"
 #include "pipeline.h"
 #include "pipeline_rfa.h"
+#include "pipeline_post.h"
 
 namespace arx {
 
@@ -73,6 +74,7 @@ template <class RT> struct Batch {
 	int done_stage = 0;
 	std::vector<int32_t> lens_host;
 	RfaResult rfa;
+	PostResult post; std::vector<size_t> post_mark;
 	std::vector<size_t> rfa_mark; bool rfa_marked = false; // arena state after ARX_STAGE_ALN: a repeated arx_batch_rfa reuses the same memory
 	explicit Batch(Context<RT> *c) : ctx(c), pipe(rt, c->ix)
 	{
@@ -164,7 +166,7 @@ template <class RT> struct Batch {
 			b->rt.set_timing(c->timing);                                                                                            \
 			/* stages already done are kept (run(SEED) then run(ALN) resumes); asking for a stage again restarts the batch */       \
 			if (last_stage <= b->done_stage) { b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; }        \
-			b->rfa_marked = false;                                                                           \
+			b->rfa_marked = false; b->post = arx::PostResult();                                                                          \
 			if (b->done_stage < ARX_STAGE_SEED) {                                                                                   \
 				int rc = b->pipe.stage_seed(b->db, b->work);                                                                        \
 				if (rc == -2) { c->set_error("batch too large: seed occurrences exceed 2^30, split the batch"); return ARX_E_TOO_LARGE; } \
@@ -207,7 +209,27 @@ template <class RT> struct Batch {
 		ARX_TRY(c, b->rt.bind(); b->rt.set_timing(c->timing);                                                                       \
 			if (b->rfa_marked) b->rt.arena_rewind(b->rfa_mark); else { b->rfa_mark = b->rt.arena_mark(); b->rfa_marked = true; }    \
 			arx::RfaStage<RT>::run(b->pipe, b->db, b->work, n_barcodes, bc_pair_off, do_rfa, penalty, cen_start, cen_end, b->lens_host.data(), b->rfa); \
+			b->post = arx::PostResult(); b->post_mark = b->rt.arena_mark();                                                         \
 			*n_cands = b->rfa.n_cands;)                                                                               \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_post(arx_ctx *h, arx_batch *bh, int64_t *n_mm)                                                                    \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (b->rfa.cand_off.empty() || !b->rfa_marked) { c->set_error("arx_batch_post before arx_batch_rfa"); return ARX_E_ARG; }   \
+		static_assert(sizeof(arx_cand_post) == sizeof(arx::CandPost) && sizeof(arx_split) == sizeof(arx::SplitRec), "C-ABI structs must mirror the device structs"); \
+		ARX_TRY(c, b->rt.bind(); b->rt.set_timing(c->timing);                                                                       \
+			b->rt.arena_rewind(b->post_mark);                                                                                       \
+			arx::PostStage<RT>::run(b->pipe, b->db, b->work, b->rfa, b->post);                                                      \
+			b->rt.sync();                                                                                                           \
+			*n_mm = b->post.n_mm;)                                                                                                  \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_post_fetch(arx_ctx *h, arx_batch *bh, arx_cand_post *post, arx_split *split, int32_t *mm_ref, int32_t *mm_read)   \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->post.done || !b->rfa_marked) { c->set_error("arx_batch_post_fetch before arx_batch_post"); return ARX_E_ARG; }      \
+		ARX_TRY(c, b->rt.bind(); arx::PostStage<RT>::fetch(b->pipe, b->db, b->rfa, b->post, (arx::CandPost *)post, (arx::SplitRec *)split, mm_ref, mm_read);) \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_rfa_fetch(arx_ctx *h, arx_batch *bh, int32_t *cand_off, arx_cand *cands)                                          \

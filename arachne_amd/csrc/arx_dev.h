@@ -16,6 +16,7 @@
 #define ARX_ATOMIC_INC(p) atomicAdd((int *)(p), 1)
 #define ARX_ATOMIC_ADD(p, v) atomicAdd((int *)(p), (int)(v))
 #define ARX_ATOMIC_MIN(p, v) atomicMin((int *)(p), (int)(v))
+#define ARX_ATOMIC_CAS(p, c, v) atomicCAS((int *)(p), (int)(c), (int)(v))
 #define ARX_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define ARX_ATOMIC_MIN64(p, v) atomicMin((long long *)(p), (long long)(v))
 #define ARX_ATOMIC_MAX64(p, v) atomicMax((long long *)(p), (long long)(v))

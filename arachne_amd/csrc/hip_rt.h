@@ -107,6 +107,7 @@ struct HipRT {
 		ARX_HIP_CHECK(hipStreamSynchronize(stream));
 	}
 	void memset0(void *d, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, 0, bytes, stream)); }
+	void memset_bytes(void *d, int v, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, v, bytes, stream)); }
 	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }
 
 	// 8 resident 64-thread blocks per CU give every SIMD two waves of these latency-bound kernels

@@ -49,6 +49,8 @@ struct KMapqPatch { Cand *cands; const int32_t *idx, *val; ARX_DEV void operator
 struct RfaResult {
 	std::vector<int32_t> cand_off; std::vector<RfaBarcodeOut> bc;
 	Cand *d_cands = nullptr; int64_t n_cands = 0; int64_t n_host_mapq = 0;
+	// kept in HBM for the passes that follow (pipeline_post.h)
+	int32_t *d_cand_off = nullptr, *d_bc_read_off = nullptr; int64_t *d_cen_start = nullptr, *d_cen_end = nullptr; int n_barcodes = 0, penalty = 0;
 };
 
 template <class RT> struct RfaStage {
@@ -113,6 +115,7 @@ template <class RT> struct RfaStage {
 		res.n_host_mapq = nf;
 		if (nf > 0) host_mapq(rt, nf, d_flag, cands, res, bro, lmp, penalty, cen_start, cen_end, lens_host);
 		res.d_cands = cands; res.n_cands = NC;
+		res.d_cand_off = cand_off; res.d_bc_read_off = d_bro; res.d_cen_start = d_cs; res.d_cen_end = d_ce; res.n_barcodes = n_barcodes; res.penalty = penalty;
 		return 0;
 	}
 

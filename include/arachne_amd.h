@@ -94,6 +94,29 @@ int arx_batch_rfa(arx_ctx *ctx, arx_batch *b, int32_t n_barcodes, const int64_t 
                   const int64_t *cen_start, const int64_t *cen_end, int64_t *n_cands);
 int arx_batch_rfa_fetch(arx_ctx *ctx, arx_batch *b, int32_t *cand_off /* n_reads+1 */, arx_cand *cands /* n_cands */);
 
+/* ---- what the reference computes per barcode between placement and the BAM records, on the candidates arx_batch_rfa left on the
+ * device (needs arx_batch_rfa first; uses its barcodes, penalty and centromeres):
+ *   the CIGAR walk of GetAlignments (aligner.go:1505-1570, against GetSeq gobwa.go:50-80): matches and the mismatch locations in
+ *   reference (contig) and read coordinates -- the host never re-fetches the reference; readmap_s/_e (gobwa.go:368-369);
+ *   markDuplicates (aligner.go:611-641); CheckSplitReads / GetSplitAlignment (split.go:31-163). */
+typedef struct {
+	int32_t qb, qe;                 /* Alignment.readmap_s / readmap_e */
+	int32_t matches;                /* Alignment.matches */
+	int32_t n_mm, mm_off;           /* Alignment.mismatchLocs / mismatchReadLocs = mm_ref / mm_read[mm_off .. mm_off + n_mm) */
+	int32_t duplicate;              /* Alignment.duplicate */
+} arx_cand_post;
+typedef struct {                    /* per read: Alignment.secondary of its active candidate */
+	int32_t split;                  /* candidate index, -1 for none */
+	int32_t mapq, is_proper;        /* split.mapq, split.is_proper */
+	int32_t n_split_cand;           /* candidates that passed split.go:85-97 */
+	int32_t order_pinned;           /* 0: > 12 such candidates with a score tie that decides the result -- Go's unstable sort.Sort picks there */
+	int32_t second_best2, score2;   /* split.mapq_data.second_best_score * 2, .score * 2 */
+	int32_t pad;
+} arx_split;
+int arx_batch_post(arx_ctx *ctx, arx_batch *b, int64_t *n_mm);
+/* post[n_cands], split[n_reads], mm_ref[n_mm], mm_read[n_mm]; any of them may be NULL */
+int arx_batch_post_fetch(arx_ctx *ctx, arx_batch *b, arx_cand_post *post, arx_split *split, int32_t *mm_ref, int32_t *mm_read);
+
 /* intermediate results for parity tests (device -> host copies of stage outputs) */
 #define ARX_CAP_INTV 256
 int arx_batch_debug_intv(arx_ctx *ctx, arx_batch *b, int32_t *n_intv, uint64_t *intv4 /* n_reads*ARX_CAP_INTV*4 */);

@@ -75,6 +75,13 @@ int64_t ora_rfa(int64_t n_reads, const int64_t *reg_off, const int64_t *regs, co
                 int n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int penalty, int64_t l_pac, const int64_t *ann_off,
                 const int64_t *cen_start, const int64_t *cen_end, int64_t *cand_rows, int64_t *cand_off);
 
+/* passes between placement and the BAM records (CIGAR walk, markDuplicates, CheckSplitReads); rows documented at the function */
+#define ORA_POST_W 6
+#define ORA_SPLIT_W 7
+int64_t ora_post(ora_ctx_t *ctx, int64_t n_reads, const int64_t *regs, const int64_t *alns, const uint32_t *cigars, const uint8_t *bases, const int32_t *lens,
+                 int n_barcodes, const int64_t *bc_pair_off, int penalty, const int64_t *ann_off, const int64_t *cen_start, const int64_t *cen_end,
+                 const int64_t *cand_rows, const int64_t *cand_off, int64_t *post_rows, int64_t *split_rows, int32_t *mm_ref, int32_t *mm_read, int64_t mm_cap);
+
 #ifdef __cplusplus
 }
 #endif

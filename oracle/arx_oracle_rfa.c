@@ -394,3 +394,167 @@ int64_t ora_rfa(int64_t n_reads, const int64_t *reg_off, const int64_t *regs, co
 	cand_off[n_reads] = total;
 	return total;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The passes between placement and the BAM records, on the rows ora_rfa wrote:
+ *   GetAlignments' CIGAR walk            aligner.go:1505-1570   (matches, mismatchLocs, mismatchReadLocs; readmap_s/_e :1620-1623)
+ *   GetSeq                                gobwa.go:50-80
+ *   markDuplicates                        aligner.go:598-641
+ *   CheckSplitReads / GetSplitAlignment   split.go:31-163
+ * sort.Sort in GetSplitAlignment is Go's pdqsort: insertion sort (stable) up to 12 elements, which is restated; above
+ * that its order among equal scores is implementation-defined, the stable order is used and order_pinned = 0 reports the
+ * reads where that choice can be seen in the result.
+ * post rows (ORA_POST_W): qb qe matches n_mm mm_off duplicate; split rows (ORA_SPLIT_W): split mapq is_proper
+ * n_split_cand order_pinned second_best2 score2.  Returns the number of mismatch locations (-1: mm_cap too small).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { int read1, reversed, rid, mrid; int64_t pos, mpos; int read; } dup_t;
+static int cmp_dup(const void *x, const void *y)
+{
+	const dup_t *a = (const dup_t*)x, *b = (const dup_t*)y;
+	if (a->read1 != b->read1) return a->read1 - b->read1;
+	if (a->reversed != b->reversed) return a->reversed - b->reversed;
+	if (a->rid != b->rid) return a->rid - b->rid;
+	if (a->mrid != b->mrid) return a->mrid - b->mrid;
+	if (a->pos != b->pos) return a->pos < b->pos ? -1 : 1;
+	if (a->mpos != b->mpos) return a->mpos < b->mpos ? -1 : 1;
+	return a->read - b->read;
+}
+static int row_is_pair(const int64_t *a, const int64_t *b) /* isPair on candidate rows */
+{
+	const int64_t *f, *r;
+	if (a[4] == b[4] || a[5] != b[5]) return 0;
+	if (a[4]) { f = b; r = a; } else { f = a; r = b; }
+	return r[2] - f[2] >= -35 && r[2] - f[2] < 750;
+}
+static int row_pair_score2(const int64_t *a, const int64_t *m, int pen2) { return (int)(a[11] + m[11]) + (row_is_pair(a, m) ? 0 : pen2); }
+
+int64_t ora_post(ora_ctx_t *ctx, int64_t n_reads, const int64_t *regs, const int64_t *alns, const uint32_t *cigars, const uint8_t *bases, const int32_t *lens,
+                 int n_barcodes, const int64_t *bc_pair_off, int penalty, const int64_t *ann_off, const int64_t *cen_start, const int64_t *cen_end,
+                 const int64_t *cand_rows, const int64_t *cand_off, int64_t *post_rows, int64_t *split_rows, int32_t *mm_ref, int32_t *mm_read, int64_t mm_cap)
+{
+	static const char two_bit_to_seq[4] = {'A','C','G','T'}, two_bit_to_seq_comp[4] = {'T','G','C','A'};
+	int64_t n_cands = cand_off[n_reads], n_mm = 0;
+	int64_t *base_off = (int64_t*)malloc((n_reads + 1) * sizeof(int64_t));
+	base_off[0] = 0;
+	for (int64_t r = 0; r < n_reads; ++r) base_off[r + 1] = base_off[r] + lens[r];
+	/* the CIGAR walk, one candidate after the other */
+	for (int64_t i = 0; i < n_cands; ++i) {
+		const int64_t *c = cand_rows + i * ORA_CAND_W;
+		int64_t *o = post_rows + i * ORA_POST_W;
+		memset(o, 0, ORA_POST_W * sizeof(int64_t));
+		o[4] = n_mm;
+		if (c[0] < 0) continue; /* placeholder: no chain, empty alignment */
+		const int64_t *rg = regs + c[0] * ORA_REG_W, *al = alns + c[0] * ORA_ALN_W;
+		int reversed = (int)c[4], l_read = lens[c[1]], n_cigar = (int)al[7];
+		int64_t ref_start = c[2], ref_end = c[3]; /* the row already carries the swap of aligner.go:1513-1516 (= :1577-1582) */
+		/* GetSeq */
+		int64_t L = ref_end - ref_start, offstart = ref_start + ann_off[c[5]], offend = ref_end + ann_off[c[5]];
+		int tid = (int)c[5];
+		char *ref_seq = (char*)calloc(L > 0 ? L : 1, 1);
+		uint8_t *two = (uint8_t*)malloc(L > 0 ? L : 1);
+		ora_fetch_seq(ctx, &offstart, (offstart + offend) >> 1, &offend, &tid, two, L);
+		for (int64_t x = 0; x < offend - offstart && x < L; ++x) {
+			if (reversed) ref_seq[offend - offstart - x - 1] = two_bit_to_seq_comp[two[x]];
+			else ref_seq[x] = two_bit_to_seq[two[x]];
+		}
+		free(two);
+		const uint8_t *rd = bases + base_off[c[1]];
+		int matches = 0, indel_length = 0, ref_off = 0, read_off = 0, cnt = 0;
+		int k = reversed ? n_cigar - 1 : 0, inc = reversed ? -1 : 1;
+		for (; k < n_cigar && k >= 0; k += inc) {
+			uint32_t cg = cigars[al[8] + k]; int op = cg & 0xf, len = cg >> 4;
+			if (op == 0) {
+				matches += len;
+				for (int m = 0; m < len; ++m) {
+					if (ref_off + m >= L) continue;
+					if (read_off + m >= l_read) continue; /* the reference panics here */
+					if (ref_seq[ref_off + m] != "ACGTN"[rd[read_off + m]]) {
+						if (n_mm >= mm_cap) { free(ref_seq); free(base_off); return -1; }
+						mm_ref[n_mm] = reversed ? (int32_t)(ref_end - (ref_off + m)) : (int32_t)(ref_off + ref_start + m);
+						mm_read[n_mm] = read_off + m;
+						++n_mm; ++cnt;
+					}
+				}
+				ref_off += len; read_off += len;
+			} else if (op == 1) { indel_length += len; read_off += len; }
+			else if (op == 2) { indel_length += len; ref_off += len; }
+			else if (op == 3) read_off += len;
+		}
+		free(ref_seq);
+		o[0] = rg[2]; o[1] = rg[3]; o[2] = matches - ((int)al[6] - indel_length); o[3] = cnt;
+	}
+	/* the active candidate of every read */
+	int64_t *act = (int64_t*)malloc((n_reads + 1) * sizeof(int64_t));
+	for (int64_t r = 0; r < n_reads; ++r) {
+		act[r] = -1;
+		for (int64_t i = cand_off[r]; i < cand_off[r + 1]; ++i) if (cand_rows[i * ORA_CAND_W + 12]) { act[r] = i; break; }
+	}
+	/* markDuplicates, barcode by barcode */
+	for (int b = 0; b < n_barcodes; ++b) {
+		int64_t r0 = 2 * bc_pair_off[b], r1 = 2 * bc_pair_off[b + 1];
+		dup_t *d = (dup_t*)malloc((r1 - r0 + 1) * sizeof(dup_t));
+		int n = 0;
+		for (int64_t r = r0; r < r1; ++r) {
+			const int64_t *a = cand_rows + act[r] * ORA_CAND_W, *m = cand_rows + act[r ^ 1] * ORA_CAND_W;
+			dup_t t; t.read1 = !(r & 1); t.reversed = (int)a[4]; t.rid = (int)a[5]; t.mrid = (int)m[5]; t.pos = a[2]; t.mpos = m[2]; t.read = (int)(r - r0);
+			d[n++] = t;
+		}
+		qsort(d, n, sizeof(dup_t), cmp_dup);
+		for (int i = 1; i < n; ++i) { dup_t x = d[i - 1]; x.read = d[i].read; if (cmp_dup(&x, &d[i]) == 0) post_rows[act[r0 + d[i].read] * ORA_POST_W + 5] = 1; }
+		free(d);
+	}
+	/* CheckSplitReads */
+	for (int64_t r = 0; r < n_reads; ++r) {
+		int64_t *o = split_rows + r * ORA_SPLIT_W;
+		memset(o, 0, ORA_SPLIT_W * sizeof(int64_t));
+		o[0] = -1; o[4] = 1;
+		const int64_t *P = cand_rows + act[r] * ORA_CAND_W, *M = cand_rows + act[r ^ 1] * ORA_CAND_W;
+		if (P[2] == -1) continue;
+		int64_t Ps = post_rows[act[r] * ORA_POST_W], Pe = post_rows[act[r] * ORA_POST_W + 1];
+		if (Ps > Pe) { int64_t t = Ps; Ps = Pe; Pe = t; }
+		if (Pe - Ps > lens[r] - 15) continue;
+		int nc = (int)(cand_off[r + 1] - cand_off[r]), n = 0;
+		int64_t *cs = (int64_t*)malloc((nc + 1) * sizeof(int64_t));
+		for (int64_t i = cand_off[r]; i < cand_off[r + 1]; ++i) {
+			const int64_t *S = cand_rows + i * ORA_CAND_W;
+			if (S[12]) continue;
+			if (S[2] == -1) continue;
+			int64_t Ss = post_rows[i * ORA_POST_W], Se = post_rows[i * ORA_POST_W + 1], overlap;
+			if (Ss > Se) { int64_t t = Ss; Ss = Se; Se = t; }
+			if ((Ps < Ss && Pe > Se) || (Ss < Ps && Se > Pe)) continue;
+			else if (Ps < Ss) overlap = Pe - Ss;
+			else overlap = Se - Ps;
+			if (overlap < (Se - Ss) / 2) {
+				int proper = row_is_pair(S, M);
+				if (S[6] >= 36 || proper) cs[n++] = i;
+			}
+		}
+		o[3] = n;
+		if (n == 0) { free(cs); continue; }
+		/* insertionSort of Go's sort package with Less(i, j) = score[i] > score[j] */
+		for (int i = 1; i < n; ++i)
+			for (int j = i; j > 0 && cand_rows[cs[j] * ORA_CAND_W + 6] > cand_rows[cs[j - 1] * ORA_CAND_W + 6]; --j) { int64_t t = cs[j]; cs[j] = cs[j - 1]; cs[j - 1] = t; }
+		const int64_t *C0 = cand_rows + cs[0] * ORA_CAND_W;
+		double mapq;
+		int pen2 = 2 * penalty;
+		if (n > 1) {
+			const int64_t *C1 = cand_rows + cs[1] * ORA_CAND_W;
+			mapq = (double)(C0[6] - C1[6]);
+			o[5] = row_pair_score2(P, C1, pen2);
+		} else {
+			mapq = (double)C0[6];
+			o[5] = (int)P[11] + pen2 + 2 * (-10) - (lens[r] - 25);
+		}
+		if (cen_start && C0[5] >= 0 && C0[2] > cen_start[C0[5]] && C0[2] <= cen_end[C0[5]]) mapq = 0.0;
+		if (mapq > 60) mapq = 60;
+		o[0] = cs[0]; o[1] = (int)mapq; o[2] = row_is_pair(C0, M); o[6] = row_pair_score2(C0, M, pen2);
+		if (n > 12) {
+			int tie0 = cand_rows[cs[1] * ORA_CAND_W + 6] == C0[6];
+			int tie1 = n > 2 && cand_rows[cs[2] * ORA_CAND_W + 6] == cand_rows[cs[1] * ORA_CAND_W + 6];
+			o[4] = !(tie0 || tie1);
+		}
+		free(cs);
+	}
+	free(act); free(base_off);
+	return n_mm;
+}

@@ -19,11 +19,13 @@
 #define ARX_ATOMIC_INC(p) ((*(p))++)
 #define ARX_ATOMIC_ADD(p, v) sim_fetch_add((p), (v))
 #define ARX_ATOMIC_MIN(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define ARX_ATOMIC_CAS(p, c, v) sim_cas((p), (c), (v))
 #define ARX_ATOMIC_ADD64(p, v) (*(p) += (v))
 #define ARX_ATOMIC_MIN64(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
 #define ARX_ATOMIC_MAX64(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 #define ARX_LOAD_SHARED(p) (*(p))
 static inline int sim_fetch_add(int32_t *p, int v) { int o = *p; *p += v; return o; }
+static inline int sim_cas(int32_t *p, int c, int v) { int o = *p; if (o == c) *p = v; return o; }
 static long sim_rescue_fast_hits = 0, sim_rescue_fast_fallbacks = 0;
 static long sim_rescue_calls = 0, sim_rescue_ins = 0, sim_rescue_skipped = 0, sim_rescue_nsum = 0, sim_rescue_nmax = 0, sim_rescue_n2sum = 0;
 static void sim_stat_rescue(int n, bool ins, int clean)
@@ -104,6 +106,7 @@ struct SimRT {
 	void h2d(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void d2h(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void memset0(void *d, size_t b) { memset(d, 0, b); }
+	void memset_bytes(void *d, int v, size_t b) { memset(d, v, b); }
 	void sync() {}
 	int max_slots() const { return 1; }
 	int max_slots_small() const { return 1; }

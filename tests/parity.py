@@ -91,3 +91,21 @@ def check_rfa(dev, ora):
         if not (a == b).all():
             i = int(np.argwhere(a != b)[0][0])
             raise AssertionError(f"candidate field {name} differs at row {i}: dev {a[i]} ora {b[i]}")
+
+
+def check_post(dev, ora):
+    """dev: Batch.post() dict; ora: rfadrv.oracle_post() dict.  Per candidate: qb/qe, matches, mismatch lists, duplicate; per read: the split record."""
+    import rfadrv
+    for col, name in enumerate(rfadrv.POST_FIELDS):
+        a, b = dev["post"][name].astype(np.int64), ora["post"][:, col]
+        if not (a == b).all():
+            i = int(np.argwhere(a != b)[0][0])
+            raise AssertionError(f"post field {name} differs at candidate {i}: dev {a[i]} ora {b[i]}")
+    assert len(dev["mm_ref"]) == len(ora["mm_ref"])
+    assert (dev["mm_ref"] == ora["mm_ref"]).all(), "mismatch reference locations differ"
+    assert (dev["mm_read"] == ora["mm_read"]).all(), "mismatch read locations differ"
+    for col, name in enumerate(rfadrv.SPLIT_FIELDS):
+        a, b = dev["split"][name].astype(np.int64), ora["split"][:, col]
+        if not (a == b).all():
+            i = int(np.argwhere(a != b)[0][0])
+            raise AssertionError(f"split field {name} differs at read {i}: dev {a[i]} ora {b[i]}")

@@ -134,6 +134,9 @@ def test_worth_running_rfa_rule():
     assert not rfadrv.worth_running_rfa("A01C02B03D04-1", 1000, unique=False)
 
 
+stats = {}
+
+
 def _device_vs_oracle(lib_path, seed):
     import oradrv
     if seed % 2:
@@ -142,6 +145,18 @@ def _device_vs_oracle(lib_path, seed):
     else:
         g = workloads.nasty_genome(seed, contig_lens=(200000, 120000, 50000), alt_contigs=2)
         rs = workloads.nasty_reads(seed, g, n_barcodes=6, pairs_per_barcode=250)
+    po = rs.pair_offsets()
+    # PCR duplicates and unmappable pairs for markDuplicates: inside every barcode some pairs become copies of another pair,
+    # some become random sequence (all their placeholders share one duplicate tuple, aligner.go:622-637)
+    rng = np.random.default_rng(900 + seed)
+    for bi in range(len(po) - 1):
+        lo, hi = int(po[bi]), int(po[bi + 1])
+        for _ in range(max(2, (hi - lo) // 20)):
+            i, j = rng.integers(lo, hi, size=2)
+            rs.seqs[2 * j:2 * j + 2] = rs.seqs[2 * i:2 * i + 2]
+            rs.lens[2 * j:2 * j + 2] = rs.lens[2 * i:2 * i + 2]
+        for j in rng.integers(lo, hi, size=3):
+            rs.seqs[2 * j:2 * j + 2] = rng.integers(0, 4, size=rs.seqs[2 * j:2 * j + 2].shape)
     d = tempfile.mkdtemp(prefix="arx_rfa_")
     fa = os.path.join(d, "g.fa")
     g.write_fasta(fa)
@@ -149,15 +164,23 @@ def _device_vs_oracle(lib_path, seed):
     api.index_build(fa, fa, lib_path=lib_path)
     o = oradrv.Oracle(fa)
     ref = api.Reference(fa, lib_path=lib_path)
-    po = rs.pair_offsets()
     flags = [rfadrv.worth_running_rfa(rs.barcodes[b], int(po[b + 1] - po[b])) for b in range(len(po) - 1)]
     flags[1] = False                                  # one barcode takes the non-RFA branch (aligner.go:469-477)
     names, offs, clens, alt, l_pac = ref.contigs()
     cen = (np.array(offs) * 0 + 1000, np.array(offs) * 0 + 30000)   # a "centromere" on every contig: MAPQ forced to 0 inside
-    ora = rfadrv.oracle_rfa(o.batch(rs.seqs, rs.lens, n_threads=4), rs.lens, po, flags, l_pac, offs, centromeres=cen)
+    ob = o.batch(rs.seqs, rs.lens, n_threads=4)
+    ora = rfadrv.oracle_rfa(ob, rs.lens, po, flags, l_pac, offs, centromeres=cen)
     b = ref.batch(rs.seqs, rs.lens).run()
     dev = b.rfa(po, flags, centromeres=cen)
     parity.check_rfa(dev, ora)
+    # the passes between placement and the BAM records: CIGAR walk, markDuplicates, CheckSplitReads
+    opost = rfadrv.oracle_post(o.h, ob, rs.seqs, rs.lens, po, offs, ora, centromeres=cen)
+    dpost = b.post()
+    parity.check_post(dpost, opost)
+    stats["n_mm"] = stats.get("n_mm", 0) + len(dpost["mm_ref"])
+    stats["dups"] = stats.get("dups", 0) + int(dpost["post"]["duplicate"].sum())
+    stats["splits"] = stats.get("splits", 0) + int((dpost["split"]["split"] >= 0).sum())
+    stats["unpinned"] = stats.get("unpinned", 0) + int((dpost["split"]["order_pinned"] == 0).sum())
     act = dev["cands"][dev["cands"]["active"] == 1]
     assert len(act) == len(rs.lens)                   # exactly one active candidate per read
     b.free()
