@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
+    ap.add_argument("--post", action="store_true", help="also run the passes between placement and the BAM records in the step (CIGAR walk with "
+                    "mismatch locations, markDuplicates, split reads: SURVEY.md s8f-3)")
     ap.add_argument("--depth", type=int, default=1, help="batch handles per chunk of the read set (steps in flight)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
@@ -256,6 +258,8 @@ def main():
                         b.run(api.STAGE_ALN)
                         if not args.no_rfa:
                             b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
+                            if args.post:
+                                b.post(fetch=False)
                     continue
                 if i > 0:
                     wait_for(seeded[s_][i - 1])
@@ -266,6 +270,8 @@ def main():
                 b.run(api.STAGE_ALN)
                 if not args.no_rfa:
                     b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
+                    if args.post:
+                        b.post(fetch=False)
         list(pool.map(worker, range(nb * len(sets))))
 
     run_steps(args.warmup)
@@ -300,7 +306,7 @@ def main():
         value = pairs_per_step * args.steps / dt
         baseline = json.load(open(os.path.join(ROOT, "BASELINE.json"))) if os.path.exists(os.path.join(ROOT, "BASELINE.json")) else {}
         out = dict(metric=baseline.get("metric", "paired reads/sec at 1/2/4/8 MI355X, GRCh38 2x150bp; CIGAR/MAPQ match vs CPU"),
-                   metric_detail="read pairs per second through the whole per-barcode path (seed + extend + rescue + CIGAR%s), results left in HBM" % ("" if args.no_rfa else " + RFA placement + MAPQ"),
+                   metric_detail="read pairs per second through the whole per-barcode path (seed + extend + rescue + CIGAR%s), results left in HBM" % ("" if args.no_rfa else " + RFA placement + MAPQ" + (" + CIGAR walk/markDuplicates/split reads" if args.post else "")),
                    value=value, unit="paired reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1000.0 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u8/i16/i32 integer (max-plus DP) + u64 (FM-index)", data="synthetic",
