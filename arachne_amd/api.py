@@ -79,6 +79,9 @@ def _load(path):
     lib.arx_batch_rfa_fetch.argtypes = [vp, vp, vp, vp]
     lib.arx_batch_post.argtypes = [vp, vp, vp]
     lib.arx_batch_post_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.arx_feeder_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp), C.c_char_p, i32]
+    lib.arx_feeder_next.argtypes = [vp, i64, vp]
+    lib.arx_feeder_close.argtypes = [vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     return lib
@@ -192,6 +195,62 @@ class Batch:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class _SuperBatch(C.Structure):
+    _fields_ = [("n_sets", C.c_int32), ("pad", C.c_int32), ("n_pairs", C.c_int64), ("bad_lines", C.c_int64), ("set_pair_off", C.c_void_p),
+                ("unique", C.c_void_p), ("do_rfa", C.c_void_p), ("bases", C.c_void_p), ("quals", C.c_void_p), ("lens", C.c_void_p),
+                ("valid", C.c_void_p), ("name_off", C.c_void_p), ("names", C.c_void_p), ("rg_off", C.c_void_p), ("rgs", C.c_void_p),
+                ("barcode_off", C.c_void_p), ("barcodes", C.c_void_p)]
+
+
+class Feeder:
+    """The reference's paired FASTQ reader (fastqreader.OpenFastQ / ReadBarcodeSet) delivering super-batches of whole barcode sets
+    (arx_feeder_*).  Host code of the product library; needs no GPU."""
+
+    def __init__(self, r1: str, r2: str, lib_path: str = LIB_PATH):
+        self.lib = _load(lib_path)
+        self.h = C.c_void_p()
+        msg = C.create_string_buffer(512)
+        if self.lib.arx_feeder_open(r1.encode(), r2.encode(), C.byref(self.h), msg, 512) != 0:
+            raise ArachneError("arx_feeder_open: " + msg.value.decode())
+
+    def next(self, target_pairs: int):
+        """-> dict (numpy copies) or None at the end of the input"""
+        sb = _SuperBatch()
+        n = self.lib.arx_feeder_next(self.h, int(target_pairs), C.byref(sb))
+        if n < 0:
+            raise ArachneError("arx_feeder_next: read error")
+        if n == 0:
+            return None
+
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(C.string_at(ptr, count * np.dtype(dt).itemsize), dtype=dt).copy()
+
+        P = sb.n_pairs
+        lens = arr(sb.lens, 2 * P, np.int32)
+        nb = int(lens.sum())
+        name_off, rg_off, bc_off = arr(sb.name_off, P + 1, np.int64), arr(sb.rg_off, P + 1, np.int64), arr(sb.barcode_off, n + 1, np.int64)
+        names, rgs, bcs = C.string_at(sb.names, int(name_off[-1])), C.string_at(sb.rgs, int(rg_off[-1])), C.string_at(sb.barcodes, int(bc_off[-1]))
+        return dict(n_sets=n, n_pairs=P, bad_lines=sb.bad_lines, set_pair_off=arr(sb.set_pair_off, n + 1, np.int64), unique=arr(sb.unique, n, np.uint8),
+                    do_rfa=arr(sb.do_rfa, n, np.uint8), bases=arr(sb.bases, nb, np.uint8), quals=C.string_at(sb.quals, nb), lens=lens,
+                    valid=arr(sb.valid, P, np.uint8),
+                    names=[names[name_off[i]:name_off[i + 1]].decode() for i in range(P)],
+                    rgs=[rgs[rg_off[i]:rg_off[i + 1]].decode() for i in range(P)],
+                    barcodes=[bcs[bc_off[i]:bc_off[i + 1]].decode() for i in range(n)])
+
+    def close(self):
+        if self.h:
+            self.lib.arx_feeder_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -29,7 +29,7 @@ extern "C" {
 typedef struct arx_ctx arx_ctx;
 typedef struct arx_batch arx_batch;
 
-enum { ARX_OK = 0, ARX_E_OPEN = -1, ARX_E_ARG = -2, ARX_E_DEVICE = -3, ARX_E_TOO_LARGE = -4 };
+enum { ARX_OK = 0, ARX_E_OPEN = -1, ARX_E_ARG = -2, ARX_E_DEVICE = -3, ARX_E_TOO_LARGE = -4, ARX_E_IO = -5 };
 
 /* last_stage values for arx_batch_run: stop after a stage to inspect intermediate results */
 enum { ARX_STAGE_SEED = 1, ARX_STAGE_CHAIN = 2, ARX_STAGE_EXTEND = 3, ARX_STAGE_RESCUE = 4, ARX_STAGE_ALN = 5 };
@@ -116,6 +116,33 @@ typedef struct {                    /* per read: Alignment.secondary of its acti
 int arx_batch_post(arx_ctx *ctx, arx_batch *b, int64_t *n_mm);
 /* post[n_cands], split[n_reads], mm_ref[n_mm], mm_read[n_mm]; any of them may be NULL */
 int arx_batch_post_fetch(arx_ctx *ctx, arx_batch *b, arx_cand_post *post, arx_split *split, int32_t *mm_ref, int32_t *mm_read);
+
+/* ---- in front of the path: the reference's paired FASTQ reader (src/fastqreader/reader.go) re-shaped to deliver super-batches of
+ * whole barcode sets -- what its producer loop (aligner.go:335-358) hands to one worker per set, one read pair per cgo call.
+ * A set is what ReadBarcodeSet (reader.go:209-300) returns: consecutive records of one barcode, at most 30000, 201-record chunks
+ * while a barcode continues across sets; `unique` is its third result (WorkUnit.unique_barcode), `do_rfa` = worthRunningRFA
+ * (aligner.go:1018-1030).  bases/lens/set_pair_off/do_rfa go straight into arx_batch_create and arx_batch_rfa; the rest is what
+ * the BAM records need.  Host code only: works without a GPU.  Pointers stay valid until the next call on the same feeder. */
+typedef struct arx_feeder arx_feeder;
+typedef struct {
+	int32_t n_sets, pad;
+	int64_t n_pairs;
+	int64_t bad_lines;              /* lines skipped while looking for a record start (reader.go:156-159), since open */
+	const int64_t *set_pair_off;    /* n_sets + 1 */
+	const uint8_t *unique, *do_rfa; /* n_sets */
+	const uint8_t *bases;           /* codes 0..4 (nst_nt4_table); read 2i / 2i+1 = Read1 / Read2 of pair i */
+	const char *quals;              /* one byte per base, same layout */
+	const int32_t *lens;            /* 2 * n_pairs */
+	const uint8_t *valid;           /* n_pairs: FastQRecord.Valid (VX:i:1) */
+	const int64_t *name_off; const char *names;       /* n_pairs + 1: FastQRecord.ReadInfo */
+	const int64_t *rg_off; const char *rgs;           /* n_pairs + 1: FastQRecord.ReadGroupId */
+	const int64_t *barcode_off; const char *barcodes; /* n_sets + 1: FastQRecord.Barcode of the set */
+} arx_super_batch;
+int arx_feeder_open(const char *r1_path, const char *r2_path, arx_feeder **out, char *msg, int32_t msg_cap); /* plain or gzip */
+/* appends whole sets until at least target_pairs pairs are held (at least one set); returns the number of sets, 0 at the end of the
+ * input, < 0 on a read error */
+int arx_feeder_next(arx_feeder *f, int64_t target_pairs, arx_super_batch *out);
+void arx_feeder_close(arx_feeder *f);
 
 /* intermediate results for parity tests (device -> host copies of stage outputs) */
 #define ARX_CAP_INTV 256
