@@ -56,14 +56,19 @@ static __global__ void __launch_bounds__(256) k_locate_dyn(IndexView ix, Seed *o
 // What happens between two runs of extensions (exporting a finished forward list, taking the next start or item) is rare per
 // lane but long, and a wavefront pays for a divergent path whenever ONE lane is in it; lanes therefore wait in front of it
 // until `batch` of them do (or nobody can extend), and the wave runs that code once for all of them.
-constexpr int SEED_ROW = 132; // bytes per lane: 256 bases + pad
+constexpr int SEED_ROW = 132; // bytes per lane for the longest read: 256 bases + pad
+// The row is as long as the batch's longest read needs (an odd number of words): LDS must not be what limits the waves per SIMD.
+inline int seed_row_bytes(int max_len) { int w = ((max_len + 1) / 2 + 3) / 4; if (!(w & 1)) ++w; return w * 4 < SEED_ROW ? w * 4 : SEED_ROW; }
+#ifndef ARX_SEED_WPE
+#define ARX_SEED_WPE 4 // waves per SIMD the seeding kernels are compiled for (register budget 512 / WPE)
+#endif
 
 struct ItemFeeder {
 	int pool_next = 0, pool_end = 0; bool exhausted = false; // wave-uniform
 	// item < 0 marks an idle lane.  tasks != nullptr: items are task ids (t0 + item), the read to stage is the task's.
 	// Returns false when nothing is left and the whole wave is idle.
 	__device__ bool deal(int &item, bool &took, const SeedTask *tasks, int t0, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
-	                     int n, int32_t *counter, int chunk, uint8_t *q_lds)
+	                     int n, int32_t *counter, int chunk, uint8_t *q_lds, int row)
 	{
 		const int lane = threadIdx.x;
 		took = false;
@@ -94,7 +99,7 @@ struct ItemFeeder {
 			if (len <= MAX_READ_LEN)
 				for (int k = 2 * lane; k < len; k += 128) {
 					const int lo = b[k], hi = k + 1 < len ? b[k + 1] : 4;
-					q_lds[src * SEED_ROW + (k >> 1)] = (uint8_t)(lo | hi << 4);
+					q_lds[src * row + (k >> 1)] = (uint8_t)(lo | hi << 4);
 				}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -107,6 +112,7 @@ struct ItemFeeder {
 struct SeedKArgs { // shared by the three kernels
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int32_t *first1; int t0;
 	int32_t *heavy; int32_t *n_heavy; int budget; // backward sweeps that exceed `budget` extensions are queued here for k_seed_bwd_wave
+	int row;                                       // bytes of LDS per lane for its read (seed_row_bytes)
 };
 
 // Lane programs: begin(item) after the read is staged (false: nothing to do), advance(req, rb, rc, slow_ok) -> has a request /
@@ -307,7 +313,7 @@ template <class Prog, bool BY_TASK>
 __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int32_t *counter, int batch, int chunk, uint8_t *q_lds)
 {
 	const int lane = threadIdx.x;
-	Prog prog(A, A.scratch + (size_t)(blockIdx.x * 64 + lane) * A.list_cap, QNibbles{q_lds + lane * SEED_ROW});
+	Prog prog(A, A.scratch + (size_t)(blockIdx.x * 64 + lane) * A.list_cap, QNibbles{q_lds + lane * A.row});
 	ItemFeeder feed;
 	int item = -1; // what this lane is working on, -1 = idle
 	Biv req = Biv();
@@ -319,7 +325,7 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 		if (waiting >= batch || waiting == 64) {
 			if (item >= 0 && !have_req && prog.done()) { prog.finish(); item = -1; }
 			bool took;
-			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
+			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds, A.row)) break;
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
 			if (Prog::ALLOCATES) { // pool slices (and task ids) for every lane that parked for them: one atomic per cursor and wave
@@ -347,28 +353,28 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 	}
 }
 
-static __global__ void __launch_bounds__(64) k_seed_fwd1(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_fwd1(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
 {
-	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	extern __shared__ uint8_t q_lds[]; // 64 rows of A.row bytes
 	persistent_lanes<FwdProg1, false>(A, n, counter, batch, chunk, q_lds);
 }
-static __global__ void __launch_bounds__(64) k_seed_fwd2(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_fwd2(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
 {
-	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	extern __shared__ uint8_t q_lds[]; // 64 rows of A.row bytes
 	persistent_lanes<FwdProg2, true>(A, n, counter, batch, chunk, q_lds);
 }
-static __global__ void __launch_bounds__(64) k_seed_bwd(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
 {
-	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	extern __shared__ uint8_t q_lds[]; // 64 rows of A.row bytes
 	persistent_lanes<BwdProg, true>(A, n, counter, batch, chunk, q_lds);
 }
 
-struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; };
+struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; int row; };
 
 // third pass: forward extensions only, no lists -- the loop body is little more than extend1()
-static __global__ void __launch_bounds__(64) k_strat_dyn(StratArgs A, int n, int32_t *counter, int chunk)
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_strat_dyn(StratArgs A, int n, int32_t *counter, int chunk)
 {
-	__shared__ uint8_t q_lds[64 * SEED_ROW];
+	extern __shared__ uint8_t q_lds[];
 	const int lane = threadIdx.x;
 	StratLane<QNibbles> ln;
 	ln.finished = true;
@@ -377,10 +383,10 @@ static __global__ void __launch_bounds__(64) k_strat_dyn(StratArgs A, int n, int
 	for (;;) {
 		if (__ballot(r < 0)) {
 			bool took;
-			if (!feed.deal(r, took, nullptr, 0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds)) break;
+			if (!feed.deal(r, took, nullptr, 0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds, A.row)) break;
 			if (took) {
 				const int len = A.lens[r];
-				if (len >= OPT_MIN_SEED_LEN && len <= MAX_READ_LEN) ln.start(len, QNibbles{q_lds + lane * SEED_ROW}, A.strat + (size_t)r * CAP_STRAT);
+				if (len >= OPT_MIN_SEED_LEN && len <= MAX_READ_LEN) ln.start(len, QNibbles{q_lds + lane * A.row}, A.strat + (size_t)r * CAP_STRAT);
 				else { A.n_strat[r] = 0; r = -1; }
 			}
 		}

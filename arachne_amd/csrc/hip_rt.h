@@ -114,11 +114,16 @@ struct HipRT {
 	int bpc = getenv("ARX_BPC") ? atoi(getenv("ARX_BPC")) : 16;           // resident 64-lane blocks per CU of the thread-per-item kernels (sizes their per-slot scratch)
 	int coop_bpc = getenv("ARX_COOP_BPC") ? atoi(getenv("ARX_COOP_BPC")) : 64; // grid cap of the 16-lane DP kernels (no per-slot scratch; grid-stride)
 	int ext_merge_below = getenv("ARX_EXT_MERGE") ? atoi(getenv("ARX_EXT_MERGE")) : 30000; // rounds with fewer extensions run all length classes in one launch
-	int strat_bpc = getenv("ARX_STRAT_BPC") ? atoi(getenv("ARX_STRAT_BPC")) : 16; // resident blocks per CU of the third seeding pass
+	int strat_bpc = getenv("ARX_STRAT_BPC") ? atoi(getenv("ARX_STRAT_BPC")) : 4 * ARX_SEED_WPE; // resident blocks per CU of the third seeding pass
 	int max_blocks() const { return n_cu * bpc; }
 	int coop_blocks(int n) const { int b = (n + 3) / 4, cap = n_cu * coop_bpc; return b < cap ? b : cap; }
 	int max_slots() const { return max_blocks() * 64; }
 	int max_slots_small() const { return n_cu * 64; }
+	// seeding kernels: 4 * ARX_SEED_WPE resident blocks per CU (their register budget is compiled for that many waves per SIMD)
+	int seed_bpc = getenv("ARX_SEED_BPC") ? atoi(getenv("ARX_SEED_BPC")) : 4 * ARX_SEED_WPE;
+	int max_seed_slots() const { return n_cu * seed_bpc * 64; }
+	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
+	void set_seed_read_len(int max_len) { seed_row = seed_row_bytes(max_len); }
 
 	// Kernel timing: a pair of HIP events around each launch on the launch stream, recorded without blocking and
 	// resolved (hipEventElapsedTime) the next time the stream is known to be idle.
@@ -227,22 +232,22 @@ struct HipRT {
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
 		int blocks = (n + 63) / 64; if (blocks > n_cu * bpc_) blocks = n_cu * bpc_;
-		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_batch, seed_chunk);
+		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, seed_batch, seed_chunk);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *counter)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0, nullptr, nullptr, 0};
-		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, bpc);
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0, nullptr, nullptr, 0, seed_row};
+		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, seed_bpc);
 	}
 	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *counter)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0, nullptr, nullptr, 0};
-		launch_seed_kernel(nm, k_seed_fwd2, n, A, counter, bpc);
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0, nullptr, nullptr, 0, seed_row};
+		launch_seed_kernel(nm, k_seed_fwd2, n, A, counter, seed_bpc);
 	}
 	template <class F> void run_seed_bwd(const char *nm, int n, const F &f, int32_t *counter)
 	{
@@ -251,8 +256,8 @@ struct HipRT {
 		// sweeps longer than seed_bwd_budget extensions are finished by whole wavefronts (k_seed_bwd_wave)
 		int32_t *heavy = alloc<int32_t>((size_t)n + 2);
 		memset0(heavy + n, 4);
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget};
-		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, bpc);
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row};
+		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, seed_bpc);
 		if (seed_bwd_budget > 0) {
 			Scope sc(*this, "seed_bwd_wave", n);
 			hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
@@ -265,9 +270,9 @@ struct HipRT {
 		if (sw_simple) { launch(nm, n, f); return; }
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
-		StratArgs A{f.ix, f.bases, f.base_off, f.lens, f.strat, f.n_strat};
+		StratArgs A{f.ix, f.bases, f.base_off, f.lens, f.strat, f.n_strat, seed_row};
 		int blocks = (n + 63) / 64; if (blocks > n_cu * strat_bpc) blocks = n_cu * strat_bpc;
-		hipLaunchKernelGGL(k_strat_dyn, dim3(blocks), dim3(64), 0, stream, A, n, counter, seed_chunk);
+		hipLaunchKernelGGL(k_strat_dyn, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, seed_chunk);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// locate: persistent lanes with wave-level work distribution (hip_fm_coop.h); 32 waves per CU to cover the miss latency

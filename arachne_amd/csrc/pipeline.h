@@ -447,7 +447,8 @@ public:
 	// ---- stage 1+2: seeding and locate.  Leaves intervals and located seeds on the device.
 	int stage_seed(const DeviceBatch &b, Work &w)
 	{
-		const int R = b.n_reads, slots = rt.max_slots(), list_cap = b.max_len + 2;
+		const int R = b.n_reads, slots = rt.max_seed_slots() > rt.max_slots() ? rt.max_seed_slots() : rt.max_slots(), list_cap = b.max_len + 2;
+		rt.set_seed_read_len(b.max_len);
 		w.err = rt.template alloc<uint32_t>(4); rt.memset0(w.err, 16);
 		w.counter = rt.template alloc<int32_t>(4);
 		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);

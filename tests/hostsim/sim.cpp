@@ -110,6 +110,8 @@ struct SimRT {
 	void sync() {}
 	int max_slots() const { return 1; }
 	int max_slots_small() const { return 1; }
+	int max_seed_slots() const { return 1; }
+	void set_seed_read_len(int) {}
 	std::map<std::string, KernelTimer> &timers() { return tm; }
 	void timers_reset(bool) { tm.clear(); }
 	template <class F> void launch(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; for (int i = 0; i < n; ++i) f(i, 0); }

@@ -21,6 +21,15 @@ for seed in range(base, base + n_seeds):
     d = tempfile.mkdtemp(prefix="arx_fuzz_"); fa = os.path.join(d, "g.fa")
     g.write_fasta(fa); g.write_alt(fa + ".alt")
     api.index_build(fa, fa)
+    po = rs.pair_offsets()
+    rng = np.random.default_rng(7000 + seed)   # PCR duplicates and unmappable pairs inside every barcode (markDuplicates)
+    for bi in range(len(po) - 1):
+        lo, hi = int(po[bi]), int(po[bi + 1])
+        for _ in range((hi - lo) // 20):
+            i, j = rng.integers(lo, hi, size=2)
+            rs.seqs[2 * j:2 * j + 2] = rs.seqs[2 * i:2 * i + 2]; rs.lens[2 * j:2 * j + 2] = rs.lens[2 * i:2 * i + 2]
+        for j in rng.integers(lo, hi, size=3):
+            rs.seqs[2 * j:2 * j + 2] = rng.integers(0, 4, size=rs.seqs[2 * j:2 * j + 2].shape)
     ref = api.load_reference(fa, 0)
     o = oradrv.Oracle(fa)
     try:
@@ -33,7 +42,9 @@ for seed in range(base, base + n_seeds):
         po = rs.pair_offsets()
         flags = [rfadrv.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(len(po) - 1)]
         names, offs, clens, alt, l_pac = ref.contigs()
-        parity.check_rfa(b.rfa(po, flags), rfadrv.oracle_rfa(ora, rs.lens, po, flags, l_pac, offs))
+        orfa = rfadrv.oracle_rfa(ora, rs.lens, po, flags, l_pac, offs)
+        parity.check_rfa(b.rfa(po, flags), orfa)
+        parity.check_post(b.post(), rfadrv.oracle_post(o.h, ora, rs.seqs, rs.lens, po, offs, orfa))
         print("seed %d ok: %d regions, %.1fs" % (seed, len(dev["regs"]), time.time() - t), flush=True)
     except AssertionError as e:
         bad += 1
