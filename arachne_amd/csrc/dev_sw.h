@@ -202,6 +202,43 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 	return r;
 }
 
+// ---- An exact pre-filter for the rescue alignment.  mem_matesw only looks at the alignment when its score reaches
+// min_seed_len = 19 (bwamem_pair.c:153); below that the call leaves no trace.  Most rescue windows sit next to a repeat copy
+// of the other read and hold nothing, so it pays to prove "score < 19" without the DP.  With match +1, mismatch -4, gaps -(6+g)
+// and no N (bwa.c:109-118, bwamem.c:48-84) take any local alignment of score S with G gaps: its G+1 gap-free segments have
+// sum(M_j - 4 X_j) = S + sum(6 + g_i) >= S + 7G (M_j matching, X_j mismatching columns).  A segment's matches fall into at most
+// X_j + 1 runs and a run of r columns holds r - 4 exact 5-mer matches on its diagonal, so the segment holds K_j >= M_j - 4 X_j - 4
+// of them and the alignment sum K_j >= S + 7G - 4(G+1) = S - 4 + 3G, on at most G+1 distinct diagonals.  With c_d the number
+// of 5-mer matches on the whole diagonal d that gives sum over those diagonals of (c_d - 3) >= S - 7, hence
+//     S >= 19  implies  sum over all diagonals of max(0, c_d - 3) >= 12.
+// ksw_u8's score is the score of some alignment (every H it forms comes from a path), so it is below 19 whenever that sum is
+// below 12.  A read with an N is never filtered (an N costs 1 and breaks runs).  Returns true when the DP has to run.
+constexpr int SWF_K = 5, SWF_NEED = 12, SWF_FREE = 3;
+ARX_DEVI bool sw_prefilter_serial(const uint8_t *q, int qlen, const uint8_t *t, int tlen)
+{
+	uint8_t head[1024], nxt[256], cnt[1056];
+	if (qlen > 255 || tlen > 800) return true;
+	for (int i = 0; i < qlen; ++i) if (q[i] > 3) return true;
+	for (int i = 0; i < 1024; ++i) head[i] = 0xff;
+	for (int i = 0; i < qlen + tlen; ++i) cnt[i] = 0;
+	for (int i = 0; i + SWF_K <= qlen; ++i) {
+		int code = 0;
+		for (int x = 0; x < SWF_K; ++x) code |= q[i + x] << (2 * x);
+		nxt[i] = head[code]; head[code] = (uint8_t)i;
+	}
+	for (int j = 0; j + SWF_K <= tlen; ++j) {
+		int code = 0;
+		for (int x = 0; x < SWF_K; ++x) code |= t[j + x] << (2 * x);
+		for (int i = head[code]; i != 0xff; i = nxt[i]) ++cnt[j - i + qlen - 1];
+	}
+	int s = 0;
+	for (int d = 0; d < qlen + tlen; ++d) if (cnt[d] > SWF_FREE) s += cnt[d] - SWF_FREE;
+	return s >= SWF_NEED;
+}
+#ifndef ARX_SW_FILTER_CHECK
+#define ARX_SW_FILTER_CHECK(pass, score) ((void)0) // the host test double checks the filter against the DP here
+#endif
+
 // ksw_align2 (ksw.c:343-365) with XBYTE: forward pass, then a pass over the reversed prefixes to find the start
 ARX_DEV U8Res u8_align(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax)
 {

@@ -65,6 +65,7 @@ struct HipRT {
 	}
 	~HipRT()
 	{
+		if (sw_filter_stats && sw_tasks_seen) fprintf(stderr, "[arx] rescue alignments queued %lld, run after the pre-filter %lld\n", (long long)sw_tasks_seen, (long long)sw_tasks_run);
 		for (auto &sl : slabs) (void)hipFree(sl.p);
 		if (scan_tmp) hipFree(scan_tmp);
 		if (d_total) hipFree(d_total);
@@ -216,12 +217,28 @@ struct HipRT {
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); return; }
-		Scope sc(*this, nm, n);
 		const int blocks = coop_blocks(n);
-		if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
-		else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n);
-		ARX_HIP_CHECK(hipGetLastError());
+		int32_t *order = nullptr, *n_order = nullptr;
+		if (sw_filter) { // tasks that provably stay below min_seed_len never reach the DP (dev_sw.h: sw_prefilter_serial)
+			order = alloc<int32_t>((size_t)n + 1); n_order = order + n;
+			memset0(n_order, 4);
+			Scope sc(*this, "sw_filter", n);
+			hipLaunchKernelGGL(k_sw_filter_g16, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order);
+			ARX_HIP_CHECK(hipGetLastError());
+		}
+		{
+			Scope sc(*this, nm, n);
+			if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order);
+			else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order);
+			ARX_HIP_CHECK(hipGetLastError());
+		}
+		if (sw_filter_stats) { int32_t k = 0; d2h(&k, n_order, 4); sw_tasks_seen += n; sw_tasks_run += k; }
 	}
+	// Off by default: on the benchmark workload 99.6 % of the rescue alignments are real hits in repeat copies (nothing to drop, the
+	// filter's 1 ms per batch is lost); on workloads with chimeric or unpaired reads it drops 40 % of them (profiles/r01/README.md).
+	int sw_filter = getenv("ARX_SW_FILTER") ? atoi(getenv("ARX_SW_FILTER")) : 0;
+	int sw_filter_stats = getenv("ARX_SW_FILTER_STATS") ? atoi(getenv("ARX_SW_FILTER_STATS")) : 0; // diagnostics: one extra host round trip per launch
+	int64_t sw_tasks_seen = 0, sw_tasks_run = 0;
 	// seeding: persistent lanes, items handed out in chunks (hip_fm_coop.h); f is one of pipeline.h's KSeedFwd1 / KSeedFwd2 / KSeedBwd,
 	// f.scratch holds max_slots() forward lists
 	int seed_batch = getenv("ARX_SEED_BATCH") ? atoi(getenv("ARX_SEED_BATCH")) : 48; // lanes that queue up before the slow bookkeeping runs

@@ -204,14 +204,80 @@ __device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_
 
 constexpr int SW_T_CAP = 800;  // rows of a rescue window: PES_HIGH - PES_LOW + MAX_READ_LEN = 784 at most
 
+// The pre-filter of dev_sw.h (sw_prefilter_serial has the derivation) by a 16-lane group: the query's 5-mers go into chained
+// lists in LDS (lane l owns the codes with code % 16 == l, so there is nothing to synchronise), the lanes walk the window's
+// 5-mers and count the hits per diagonal in byte counters (LDS atomics on the containing word: a diagonal holds at most 245).
+// Tasks that need the DP are appended to `order`; the others get a result that says "below min_seed_len" right away.
+struct SwFilterLds { uint8_t tl[SW_T_CAP / 2]; uint8_t q[256]; uint8_t head[1024]; uint8_t nxt[256]; uint32_t cnt[(SW_T_CAP + 256) / 4]; };
+
+static __global__ void __launch_bounds__(64) k_sw_filter_g16(IndexView ix, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
+                                                             const SwTask *tasks, U8Res *res, int n, int32_t *order, int32_t *n_order)
+{
+	__shared__ SwFilterLds L[4];
+	const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+	SwFilterLds &S = L[g];
+	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
+		const SwTask t = tasks[i];
+		const int r = 2 * t.pair + t.o, l_ms = lens[r], tlen = (int)(t.re - t.rb);
+		const uint8_t *mate = bases + base_off[r];
+		bool has_n = l_ms > 255 || tlen > SW_T_CAP;
+		if (!has_n) {
+			sw_stage_target(ix, t.rb, tlen, S.tl);
+			for (int k = l; k < l_ms; k += 16) { const int b = mate[l_ms - 1 - k]; S.q[k] = (uint8_t)(b < 4 ? 3 - b : 4); has_n |= b > 3; } // the reverse complement, as the DP reads it
+			for (int w = l; w < 256; w += 16) ((uint32_t *)S.head)[w] = 0xffffffffu;
+			for (int w = l; w < (SW_T_CAP + 256) / 4; w += 16) S.cnt[w] = 0;
+		}
+		has_n = (__ballot(has_n) >> (g * 16) & 0xffff) != 0;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		int s = 0;
+		if (!has_n) {
+			int code = 0;
+			for (int k = 0; k < l_ms; ++k) { // every lane rolls over the whole query and files the positions whose code it owns
+				code = code >> 2 | S.q[k] << 8;
+				if (k >= SWF_K - 1 && (code & 15) == l) { const int p = k - (SWF_K - 1); S.nxt[p] = S.head[code]; S.head[code] = (uint8_t)p; }
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			for (int j = l; j + SWF_K <= tlen; j += 16) {
+				int c = 0;
+#pragma unroll
+				for (int x = 0; x < SWF_K; ++x) { const int k = j + x; c |= ((S.tl[k >> 1] >> ((k & 1) << 2)) & 3) << (2 * x); }
+				for (int p = S.head[c]; p != 0xff; p = S.nxt[p]) {
+					const int d = j - p + l_ms - 1;
+					atomicAdd(&S.cnt[d >> 2], 1u << ((d & 3) << 3));
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			for (int w = l; w < (l_ms + tlen + 3) / 4; w += 16) {
+				const uint32_t x = S.cnt[w];
+#pragma unroll
+				for (int b = 0; b < 4; ++b) { const int c = (int)(x >> (8 * b) & 255) - SWF_FREE; s += c > 0 ? c : 0; }
+			}
+			for (int m = 8; m; m >>= 1) s += __shfl_xor(s, m, 16);
+		}
+		if (l == 0) {
+			if (has_n || s >= SWF_NEED) order[atomicAdd(n_order, 1)] = i;
+			else { U8Res none; none.score = 0; none.te = none.qe = none.score2 = none.te2 = none.tb = none.qb = -1; res[t.slot] = none; }
+		}
+		__builtin_amdgcn_wave_barrier(); // the LDS block is reused by the group's next task
+	}
+}
+
 template <int SL>
 __global__ void __launch_bounds__(64) k_sw_u8_g16(IndexView ix, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
-                                                  const SwTask *tasks, U8Res *res, int n)
+                                                  const SwTask *tasks, U8Res *res, int n, const int32_t *order, const int32_t *n_order)
 {
 	__shared__ uint8_t rowmax_lds[4][SW_T_CAP];
 	__shared__ uint8_t target_lds[4][SW_T_CAP / 2];
 	const int g = threadIdx.x >> 4;
-	for (int i = blockIdx.x * 4 + g; i < n; i += gridDim.x * 4) {
+	if (order) n = *n_order; // the tasks the pre-filter left
+	for (int x = blockIdx.x * 4 + g; x < n; x += gridDim.x * 4) {
+		const int i = order ? order[x] : x;
 		const SwTask t = tasks[i];
 		const int r = 2 * t.pair + t.o;
 		sw_u8_align_g16<SL>(ix, bases + base_off[r], lens[r], t.rb, (int)(t.re - t.rb), rowmax_lds[g], target_lds[g], &res[t.slot]);

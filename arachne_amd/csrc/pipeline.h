@@ -318,6 +318,7 @@ struct KSwU8 {
 		for (int k = 0; k < l_ms; ++k) { int b = ms[k]; qbuf[l_ms - 1 - k] = b < 4 ? 3 - b : 4; } // reverse complement of the mate (bwamem_pair.c:134-137)
 		for (int k = 0; k < tlen; ++k) tbuf[k] = (uint8_t)ref_base(ix, t.rb + k);
 		res[t.slot] = u8_align(qbuf, l_ms, tbuf, tlen, KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A), row, stride, rowmax);
+		ARX_SW_FILTER_CHECK(sw_prefilter_serial(qbuf, l_ms, tbuf, tlen), res[t.slot].score);
 	}
 };
 

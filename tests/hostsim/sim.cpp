@@ -34,6 +34,15 @@ static void sim_stat_rescue(int n, bool ins, int clean)
 }
 struct SimStatPrinter { ~SimStatPrinter() { if (getenv("ARX_RESCUE_STATS")) fprintf(stderr, "[sim] rescue applies %ld, inserted %ld, dedup skipped %ld, mean n %.1f, mean n^2 %.1f, max n %ld; fast inserts %ld, fallbacks %ld\n", sim_rescue_calls, sim_rescue_ins, sim_rescue_skipped, sim_rescue_calls ? (double)sim_rescue_nsum / sim_rescue_calls : 0.0, sim_rescue_calls ? (double)sim_rescue_n2sum / sim_rescue_calls : 0.0, sim_rescue_nmax, sim_rescue_fast_hits, sim_rescue_fast_fallbacks); } } sim_stat_printer;
 #define ARX_STAT_RESCUE(pair, n, inserts, clean) sim_stat_rescue((n), (inserts), (clean))
+// the rescue pre-filter against the DP it replaces: a filtered task must score below min_seed_len (always checked)
+static long sim_swf_tasks = 0, sim_swf_filtered = 0, sim_swf_low = 0;
+static void sim_sw_filter_check(bool pass, int score)
+{
+	++sim_swf_tasks; sim_swf_filtered += !pass; sim_swf_low += score < 19;
+	if (!pass && score >= 19) { fprintf(stderr, "[sim] rescue pre-filter dropped an alignment of score %d\n", score); abort(); }
+}
+struct SimSwfPrinter { ~SimSwfPrinter() { if (getenv("ARX_RESCUE_STATS")) fprintf(stderr, "[sim] rescue SWs %ld, below min_seed_len %ld, filtered %ld\n", sim_swf_tasks, sim_swf_low, sim_swf_filtered); } } sim_swf_printer;
+#define ARX_SW_FILTER_CHECK(pass, score) sim_sw_filter_check((pass), (score))
 static long sim_bwd_hist_n[8], sim_bwd_hist_ext[8], sim_bwd_ext_by_n[8], sim_bwd_max_ext;
 static void sim_stat_bwd(int n, int ext)
 {
@@ -148,3 +157,6 @@ struct SimRT {
 
 #include "../../arachne_amd/csrc/api_impl.h"
 ARX_DEFINE_C_API(arx::SimRT)
+
+// test entry: the rescue pre-filter alone (tests/test_sw_prefilter.py checks it against the oracle's ksw_align2)
+extern "C" int arx_test_sw_prefilter(const uint8_t *q, int qlen, const uint8_t *t, int tlen) { return arx::sw_prefilter_serial(q, qlen, t, tlen) ? 1 : 0; }

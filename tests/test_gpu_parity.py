@@ -60,12 +60,15 @@ def test_ragged_and_degenerate_reads(env):
     parity.check_final(ref.mem_mate_sw(flat, lens), o.batch(flat, lens))
 
 
-@pytest.mark.parametrize("seed,no_ahead", [(21, False), (22, False), (22, True)])
-def test_fresh_nasty_workload_matches_oracle_and_reference(built, seed, no_ahead, monkeypatch):
-    """no_ahead: every rescue SW takes the one-at-a-time path instead of the queued-ahead launch (pipeline.h stage_rescue)."""
+@pytest.mark.parametrize("seed,no_ahead,sw_filter", [(21, False, False), (22, False, False), (22, True, False), (21, False, True), (23, False, True)])
+def test_fresh_nasty_workload_matches_oracle_and_reference(built, seed, no_ahead, sw_filter, monkeypatch):
+    """no_ahead: every rescue SW takes the one-at-a-time path instead of the queued-ahead launch (pipeline.h stage_rescue).
+    sw_filter: rescue alignments that provably stay below min_seed_len never reach the DP (k_sw_filter_g16; off by default)."""
     import oradrv
     if no_ahead:
         monkeypatch.setenv("ARX_RESCUE_NO_AHEAD", "1")
+    if sw_filter:
+        monkeypatch.setenv("ARX_SW_FILTER", "1")
     g = workloads.nasty_genome(seed, contig_lens=(200000, 120000, 50000), alt_contigs=2)
     rs = workloads.nasty_reads(seed, g, n_barcodes=8, pairs_per_barcode=500)
     tmp = tempfile.mkdtemp(prefix="arx_gpu_nasty_")
