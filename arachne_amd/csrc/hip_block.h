@@ -1,4 +1,4 @@
-// hip_block.h -- workgroup-cooperative primitives for kernels that give one work item (a barcode) to a whole 256-lane
+// hip_block.h -- workgroup-cooperative primitives for kernels that give one work item (a barcode) to a whole 1024-lane
 // workgroup: strided parallel-for with barrier, block scan, bitonic key/value sort, arg-max.  The device logic written
 // against this handle (dev_rfa.h) keeps its control flow uniform over the workgroup.
 #pragma once
@@ -7,7 +7,10 @@
 
 namespace arx {
 
-constexpr int BLOCK_LANES = 256, SORT_LDS = 4096;
+#ifndef ARX_BLOCK_LANES
+#define ARX_BLOCK_LANES 1024 // 6.4 ms (256) -> 4.3 (512) -> 3.8 (1024) per 350 k-pair batch: a barcode is one workgroup and the kernel is latency-bound
+#endif
+constexpr int BLOCK_LANES = ARX_BLOCK_LANES, SORT_LDS = 4096;
 
 struct HipBlock {
 	int tid;
@@ -32,12 +35,16 @@ struct HipBlock {
 		for (int i = b; i < e; ++i) sum += in[i];
 		l32[tid] = sum;
 		__syncthreads();
-		if (tid < 64) { // one wave scans the 256 partial sums, 4 per lane
-			int a0 = l32[4 * tid], a1 = l32[4 * tid + 1], a2 = l32[4 * tid + 2], a3 = l32[4 * tid + 3];
-			int t = a0 + a1 + a2 + a3, incl = t;
+		if (tid < 64) { // one wave scans the partial sums, BLOCK_LANES / 64 per lane
+			constexpr int PER = BLOCK_LANES / 64;
+			int a[PER], t = 0;
+#pragma unroll
+			for (int x = 0; x < PER; ++x) { a[x] = l32[PER * tid + x]; t += a[x]; }
+			int incl = t;
 			for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
 			int ex = incl - t;
-			l32[4 * tid] = ex; l32[4 * tid + 1] = ex + a0; l32[4 * tid + 2] = ex + a0 + a1; l32[4 * tid + 3] = ex + a0 + a1 + a2;
+#pragma unroll
+			for (int x = 0; x < PER; ++x) { l32[PER * tid + x] = ex; ex += a[x]; }
 			if (tid == 63) l32[BLOCK_LANES] = incl;
 		}
 		__syncthreads();

@@ -194,7 +194,7 @@ struct HipRT {
 		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
-	// one work item per 256-lane workgroup (hip_block.h); f(item, HipBlock&)
+	// one work item per BLOCK_LANES-lane workgroup (hip_block.h); f(item, HipBlock&)
 	template <class F> void launch_block(const char *nm, int n, const F &f)
 	{
 		if (n <= 0) return;
