@@ -82,45 +82,62 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		Q4[j] = 4 * ((j < slen && k < qlen) ? sq.q(k) : 5);
 	}
 	int gmax = 0, te = -1, hlast = 0, rows = 0;
-	for (int i = 0; i < tlen; ++i) {
+	// one row: reads the previous row's H from Hin, leaves this row's in Hout; the caller alternates the two arrays so that no
+	// row ends with a register copy per cell.  Returns true when the pass stops after this row.
+	auto row = [&](const int (&Hin)[SL], int (&Hout)[SL], int i) __attribute__((always_inline)) -> bool {
 		const uint32_t W = u8_score_word(sq.t(i));
 		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
 		// straight-line select code over all SL stripes: stripes past slen (a shorter query in the second pass) come last in
-		// the chain, so what they compute flows nowhere as long as they leave f and the row maximum alone
+		// the chain, so what they compute flows nowhere as long as they leave f and the row maximum alone.
+		// _mm_adds_epu8(h, profile) cannot saturate (h <= 249 for reads below 250 bases, profile <= 5), and the floor of
+		// _mm_subs_epu8(h, shift) comes for free from E, f >= 0 in the three-way maximum; both gap states take the floor of their
+		// saturating subtractions as the third operand of a v_max3
 #pragma unroll
 		for (int j = 0; j < SL; ++j) {
 			const bool valid = j < slen;
 			const int s = (int)((W >> Q4[j]) & 15u);
-			int hh = h + s - 4;                           // _mm_adds_epu8 then _mm_subs_epu8(h, shift): min(h + s, 255) - 4, not below 0
-			hh = hh < 0 ? 0 : (hh > 251 ? 251 : hh);
-			hh = hh > E[j] ? hh : E[j];
-			hh = hh > f ? hh : f;
-			const int hm = valid ? hh : 0;
-			mx = mx > hm ? mx : hm;
-			H1[j] = hh;
-			int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;         // subs(h, oe): o+e = 7 for both gap kinds
-			const int e1 = E[j] - 1;                       // t7 >= 0 covers the saturation of E - 1 at 0
-			E[j] = e1 > t7 ? e1 : t7;
-			const int f1 = f - 1;
-			const int fn = f1 > t7 ? f1 : t7;
+			const int hd = h + s - 4;
+			const int he = hd > E[j] ? hd : E[j];
+			const int hh = he > f ? he : f;
+			Hout[j] = hh;
+			const int h7 = hh - 7;                         // subs(h, oe): o + e = 7 for both gap kinds
+			const int e1 = E[j] - 1, em = e1 > h7 ? e1 : h7;
+			E[j] = em > 0 ? em : 0;
+			const int f1 = f - 1, fm = f1 > h7 ? f1 : h7;
+			const int fn = fm > 0 ? fm : 0;
 			f = valid ? fn : f;
-			h = H0[j];
+			h = Hin[j];
 		}
-		// lazy-F (ksw.c:177-189)
-		{
-			bool stop = false;
-			for (int k2 = 0; k2 < 16 && !stop; ++k2) {
-				f = g16_shift_up(f, l);
 #pragma unroll
-				for (int j = 0; j < SL; ++j) {
-					if (j < slen && !stop) {
-						int hh = H1[j] > f ? H1[j] : f;
-						H1[j] = hh;
-						int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;
-						f = f - 1; f = f > 0 ? f : 0;
-						if (g16_all(!(f > t7))) stop = true;
+		for (int j = 0; j < SL; ++j) { const int hm = j < slen ? Hout[j] : 0; mx = mx > hm ? mx : hm; }
+		// lazy-F (ksw.c:177-189).  Its first step nearly always ends it: that step is straight-line code, the general loop (which
+		// carries the whole row of H through its iterations) sits behind a branch
+		{
+			bool stop;
+			f = g16_shift_up(f, l);
+			{
+				const int hh = Hout[0] > f ? Hout[0] : f;
+				Hout[0] = hh;
+				int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;
+				f = f - 1; f = f > 0 ? f : 0;
+				stop = g16_all(!(f > t7));
+			}
+			if (!stop) {
+				for (int k2 = 0; k2 < 16 && !stop; ++k2) {
+					if (k2) f = g16_shift_up(f, l);
+#pragma unroll
+					for (int j = 0; j < SL; ++j) {
+						if (j < slen && !stop && (k2 || j)) {
+							int hh = Hout[j] > f ? Hout[j] : f;
+							Hout[j] = hh;
+							int t7 = hh - 7; t7 = t7 > 0 ? t7 : 0;
+							f = f - 1; f = f > 0 ? f : 0;
+							if (g16_all(!(f > t7))) stop = true;
+						}
 					}
 				}
+#pragma unroll
+				for (int j = 0; j < SL; ++j) { const int hm = j < slen ? Hout[j] : 0; mx = mx > hm ? mx : hm; }
 			}
 		}
 		const int imax = g16_max(mx);
@@ -130,12 +147,16 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		if (imax > gmax) {
 			gmax = imax; te = i;
 #pragma unroll
-			for (int j = 0; j < SL; ++j) HM[j] = H1[j];
+			for (int j = 0; j < SL; ++j) HM[j] = Hout[j];
 			if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
 		}
-		if (brk) break;
 #pragma unroll
-		for (int j = 0; j < SL; ++j) { H0[j] = H1[j]; if (j == slen - 1) hlast = H1[j]; }
+		for (int j = 0; j < SL; ++j) if (j == slen - 1) hlast = Hout[j];
+		return brk;
+	};
+	for (int i = 0; i < tlen; i += 2) {
+		if (row(H0, H1, i)) break;
+		if (i + 1 < tlen && row(H1, H0, i + 1)) break;
 	}
 	U8Res r;
 	r.score = gmax + 4 < 255 ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
