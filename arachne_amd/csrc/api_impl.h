@@ -21,6 +21,15 @@ namespace arx {
 
 template <class RT> struct Batch;
 
+// SA[i * d] for every i: the suffix-array sample the locate kernel walks to.  The files sample every 32nd row (bwt.c:62,
+// bwtindex.c:309); bwt_sa's LF walk from a row to the next sampled one (bwt.c:86-96) is what locating a seed costs, 15.5 steps on
+// average.  A sample every `d`-th row, computed once per arx_open on the device with that same walk, gives the same values in
+// (d - 1) / 2 steps.
+struct KSaDense {
+	IndexView ix; uint64_t *out; int d;
+	ARX_DEV void operator()(int i, int) const { out[i] = sa_lookup(ix, (uint64_t)i * (uint64_t)d); }
+};
+
 template <class RT> struct Context {
 	RT rt;                      // index uploads
 	int device = 0;
@@ -58,6 +67,20 @@ template <class RT> struct Context {
 		ix.primary = hix.primary; ix.seq_len = hix.seq_len;
 		for (int i = 0; i < 5; ++i) ix.L2[i] = hix.L2[i];
 		ix.l_pac = hix.l_pac; ix.n_seqs = (int)hix.names.size(); ix.sa_intv = hix.sa_intv;
+		{ // denser suffix-array sample (ARX_SA_DENSE: rows per sample, a power of two; at least the file's interval switches it off)
+			const char *e = getenv("ARX_SA_DENSE");
+			const int d = e ? atoi(e) : 8;
+			const uint64_t n2 = (ix.seq_len + (uint64_t)d) / (uint64_t)d;
+			if (d >= 1 && d < ix.sa_intv && (d & (d - 1)) == 0 && n2 < 0x7fffffffull) {
+				uint64_t *dense = rt.template palloc<uint64_t>((size_t)n2 + 8);
+				KSaDense kd{ix, dense, d};
+				rt.launch_wide("sa_dense", (int)n2, kd);
+				rt.sync();
+				void *old = (void *)ix.sa;
+				for (auto &p : dev_index) if (p == old) { rt.pfree(p); p = dense; }
+				ix.sa = dense; ix.sa_intv = d;
+			}
+		}
 		for (auto &n : hix.names) name_ptrs.push_back(n.c_str());
 		return "";
 	}

@@ -377,7 +377,9 @@ def main():
                 avg_ms = kl["ms"] / kl["calls"]
                 ach = ab["locate"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
                 out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                                              frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms)
+                                              frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms,
+                                              note="algorithmic bytes are those of the reference's walk to a sample every 32nd row; the device walks to the sample "
+                                                   "every %s-th row it builds at arx_open and moves about a quarter of them" % os.environ.get("ARX_SA_DENSE", "8"))
             out["work_per_read"] = ab["counters"]
         except Exception as e:  # the roofline needs the oracle library; never fail the throughput line over it
             log("roofline skipped:", repr(e))
