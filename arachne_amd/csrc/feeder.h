@@ -136,33 +136,34 @@ public:
 		return 1;
 	}
 
-	// ReadBarcodeSet: appends the set's records to `out`; returns 1 (a set, `unique` set), 0 (end of input), -1 (read error)
-	int read_barcode_set(std::vector<FastqRecord> &out, bool &unique)
+	// ReadBarcodeSet: the set's records are out[0 .. n) (the vector only grows: its strings keep their storage from set to set);
+	// returns 1 (a set, `unique` and `n` set), 0 (end of input), -1 (read error)
+	int read_barcode_set(std::vector<FastqRecord> &out, size_t &n, bool &unique)
 	{
-		out.clear();
+		n = 0;
 		unique = false;
 		if (deferred_) return deferred_ == 1 ? 0 : -1;
 		bool new_barcode = false;
 		size_t index = 0;
-		if (have_pending_) { out.push_back(pending_); have_pending_ = false; index = 1; }
+		auto slot = [&](size_t i) -> FastqRecord & { if (i == out.size()) out.emplace_back(); return out[i]; };
+		if (have_pending_) { std::swap(slot(0), pending_); have_pending_ = false; index = 1; }
+		n = index;
 		for (; index < 30000; ++index) {
-			out.emplace_back();
-			const int rc = read_one(out[index]);
-			if (rc <= 0) {
-				out.pop_back(); // the record the reference leaves half-filled and then cuts off (or, for a read error, hands on)
+			const int rc = read_one(slot(index));
+			if (rc <= 0) { // the record the reference leaves half-filled and then cuts off (or, for a read error, hands on) is not counted
 				if (index == 0) { deferred_ = rc == 0 ? 1 : 2; return rc == 0 ? 0 : -1; }
 				deferred_ = rc == 0 ? 1 : 2;
 				break;
 			}
 			if (out[0].barcode != out[index].barcode) {
-				pending_ = out[index]; have_pending_ = true; out.pop_back();
+				std::swap(pending_, out[index]); have_pending_ = true;
 				new_barcode = true;
 				break;
-			} else if (have_last_ && out[0].barcode == last_barcode_ && index >= 200) {
-				break; // "abnormal break": the 201st record stays in the set
 			}
+			n = index + 1;
+			if (have_last_ && out[0].barcode == last_barcode_ && index >= 200) break; // "abnormal break": the 201st record stays in the set
 		}
-		if (!out.empty()) { last_barcode_ = out[0].barcode; have_last_ = true; }
+		if (n) { last_barcode_ = out[0].barcode; have_last_ = true; }
 		unique = new_barcode || deferred_ == 1;
 		return 1;
 	}
@@ -176,19 +177,21 @@ public:
 		int rc = 1;
 		while (pairs < target_pairs || set_off_.size() == 1) {
 			bool unique;
-			rc = read_barcode_set(set_, unique);
+			size_t n_set;
+			rc = read_barcode_set(set_, n_set, unique);
 			if (rc <= 0) break;
-			for (const FastqRecord &r : set_) {
+			for (size_t k = 0; k < n_set; ++k) {
+				const FastqRecord &r = set_[k];
 				append_read(r.s1, r.q1); append_read(r.s2, r.q2);
 				names_ += r.info; name_off_.push_back((int64_t)names_.size());
 				rgs_ += r.rg; rg_off_.push_back((int64_t)rgs_.size());
 				valid_.push_back(r.valid);
 			}
-			pairs += (int64_t)set_.size();
+			pairs += (int64_t)n_set;
 			set_off_.push_back(pairs);
 			unique_.push_back(unique);
 			const std::string &bc = set_[0].barcode;
-			do_rfa_.push_back(unique && bc.find('-') != std::string::npos && set_.size() >= 5); // worthRunningRFA
+			do_rfa_.push_back(unique && bc.find('-') != std::string::npos && n_set >= 5); // worthRunningRFA
 			bcs_ += bc; bc_off_.push_back((int64_t)bcs_.size());
 		}
 		if (rc < 0 && set_off_.size() == 1) { error = "read error in the FASTQ input"; return -1; }
