@@ -142,8 +142,8 @@ def algorithmic_bytes(prefix, rs, n_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--barcodes", type=int, default=1000)
     ap.add_argument("--pairs-per-barcode", type=int, default=1000)
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)

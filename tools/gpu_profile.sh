@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --no-cpu-baseline"   # the default command (K = 10 timed steps after 2 warm-up steps) minus the CPU leg
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err   # also warms the index cache in /tmp
 echo "plain rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
