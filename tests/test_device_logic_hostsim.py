@@ -98,10 +98,20 @@ def test_argument_errors(env):
         b.rfa([0, 20], [True])                            # placement before the alignment stage
     b.run()
     with pytest.raises(api.ArachneError):
+        b.post()                                          # the post-placement passes before the placement
+    with pytest.raises(api.ArachneError):
         b.rfa([0, 10], [True])                            # barcode offsets must cover the batch
     with pytest.raises(api.ArachneError):
         b.rfa([5, 20], [True])
     assert len(b.rfa([0, 20], [False])["cands"]) >= 40    # still usable afterwards
+    p1 = b.post()
+    assert len(p1["split"]) == 40 and (p1["post"]["qe"] >= p1["post"]["qb"]).all()
+    b.run()                                               # running the batch again invalidates placement and post results
+    with pytest.raises(api.ArachneError):
+        b.post()
+    b.rfa([0, 20], [False])
+    p2 = b.post()                                         # ... and the same calls give the same answer again
+    assert p1["post"].tobytes() == p2["post"].tobytes() and p1["split"].tobytes() == p2["split"].tobytes()
     b.free()
     with pytest.raises(api.ArachneError):
         ref.batch(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32))   # an empty batch is refused, not crashed on
