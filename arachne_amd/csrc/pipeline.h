@@ -251,11 +251,16 @@ struct KExtend {
 struct KDedup {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const int32_t *n_ext; Reg *regs, *tmp; int32_t *idx;
 	int32_t *eh; int eh_words; int32_t *n_core;
+	int32_t *clean; // what the rescue stage may assume about the list (matesw_apply): 2 = went through the pass with >= 2 regions and nothing was merged,
+	                // so it is a fixed point of the pass mem_matesw repeats; 1 = fewer than two regions; 0 = a merge happened, nothing is known
 	ARX_DEV void operator()(int r, int slot) const
 	{
 		const int g0 = occ_off[r];
 		int n = n_ext[r];
-		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words);
+		int32_t patched = 0;
+		clean[r] = n >= 2 ? 2 : 1;
+		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words, &patched);
+		if (patched) clean[r] = 0;
 		for (int i = 0; i < n; ++i) { Reg &p = regs[g0 + i]; if (p.rid >= 0 && ix.ann_alt[p.rid]) p.is_alt = 1; }
 		n_core[r] = n;
 	}
@@ -274,12 +279,13 @@ struct KPairCap {
 };
 
 struct KPairInit {
-	const int32_t *occ_off, *n_core, *preg_off; const Reg *regs; Reg *pregs; int32_t *n_regs; ResState *state;
+	const int32_t *occ_off, *n_core, *preg_off; const Reg *regs; Reg *pregs; int32_t *n_regs; ResState *state; const int32_t *core_clean;
 	ARX_DEV void operator()(int p, int) const
 	{
 		ResState st = ResState();
 		for (int e = 0; e < 2; ++e) {
 			const int r = 2 * p + e, n = n_core[r];
+			st.clean[e] = core_clean[r]; // the list mem_align1_core left is usually already a fixed point of mem_matesw's pass (KDedup)
 			int best = 0;
 			for (int i = 0; i < n; ++i) { Reg x = regs[occ_off[r] + i]; pregs[preg_off[r] + i] = x; if (x.score > best) best = x.score; }
 			n_regs[r] = n; st.best[e] = best;
@@ -423,7 +429,7 @@ public:
 
 	// everything that stays on the device between the stages of one batch
 	struct Work {
-		Biv *intv = 0, *smem_scr = 0; int32_t *n_intv = 0, *n_occ = 0, *occ_off = 0; Seed *occ_seed = 0;
+		Biv *intv = 0, *smem_scr = 0; int32_t *n_intv = 0, *n_occ = 0, *occ_off = 0; Seed *occ_seed = 0; int32_t *core_clean = 0;
 		int32_t *next = 0, *iscr = 0, *n_chain = 0, *srt = 0, *idx = 0, *n_core = 0; Chain *ctmp = 0, *cout = 0; BtNode *nodes = 0; Seed *sout = 0;
 		Reg *regs = 0, *rtmp = 0; ExtState *est = 0; ExtTask *etask = 0; ExtRes *eres = 0; int32_t *counter = 0; uint32_t *err = 0;
 		int32_t *eh = 0; int32_t *cap = 0, *preg_off = 0, *n_regs = 0, *pidx = 0; Reg *pregs = 0, *ptmp = 0; ResState *rst = 0; SwTask *stask = 0; U8Res *sres = 0;
@@ -514,7 +520,7 @@ public:
 	{
 		const int R = b.n_reads; const size_t T = (size_t)w.T + 1; const int slots = rt.max_slots();
 		w.srt = rt.template alloc<int32_t>(T); w.regs = rt.template alloc<Reg>(T); w.rtmp = rt.template alloc<Reg>(T); w.idx = rt.template alloc<int32_t>(T);
-		w.n_core = rt.template alloc<int32_t>(R + 1);
+		w.n_core = rt.template alloc<int32_t>(R + 1); w.core_clean = rt.template alloc<int32_t>(R + 1);
 		const int eh_words = 2 * (b.max_len + 2);
 		w.eh = rt.template alloc<int32_t>((size_t)slots * eh_words);
 		// one state machine per chain (dev_regs.h): chain gids by a scan of the per-read chain counts
@@ -550,7 +556,7 @@ public:
 		KExtGather kg{w.occ_off, w.n_chain, chain_off, w.cout, w.est, pool, w.regs, n_ext};
 		rt.launch_wide("ext_gather", R, kg);
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
-		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core};
+		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, w.core_clean};
 		rt.launch_cold("dedup", R, kd);
 	}
 
@@ -570,7 +576,7 @@ public:
 		rt.memset0(n_slots, 8);
 		const int q_cap = (b.max_len + 15) & ~15, t_cap = (PES_HIGH - PES_LOW + 2 * b.max_len + 31) & ~15;
 		w.sw_scr = rt.template alloc<uint8_t>((size_t)slots * (q_cap + 2 * t_cap));
-		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst};
+		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst, w.core_clean};
 		rt.launch_wide("pair_init", NP, ki);
 		for (int round = 0;; ++round) {
 			rt.memset0(w.counter, 4);
