@@ -5,5 +5,5 @@ run() { echo "== $*"; env "$@" timeout -k 10 200 python tools/gpu_rounds.py 350 
 run X=default
 for b in 16 32 64; do run ARX_SEED_BATCH=$b; done
 for c in 16 256; do run ARX_SEED_CHUNK=$c; done
-for b in 4 8 12 19; do run ARX_BPC=$b; done
-for b in 96 192; do run ARX_SEED_BWD_BUDGET=$b; done
+for b in 8 12 20; do run ARX_SEED_BPC=$b ARX_STRAT_BPC=$b; done
+for b in 64 96 192 256; do run ARX_SEED_BWD_BUDGET=$b; done
