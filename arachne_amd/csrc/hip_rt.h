@@ -245,13 +245,15 @@ struct HipRT {
 	int seed_bwd_budget = getenv("ARX_SEED_BWD_BUDGET") ? atoi(getenv("ARX_SEED_BWD_BUDGET")) : 128; // extensions a lane spends on one backward sweep before handing it to a wavefront (0: never)
 	int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64; // items a wavefront reserves per atomic
 	int seed_bwd_chunk = getenv("ARX_SEED_BWD_CHUNK") ? atoi(getenv("ARX_SEED_BWD_CHUNK")) : (getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 32); // backward sweeps vary most in length: smaller reservations even out the end of the launch (64: 10.3 ms, 32: 9.4, 16: 9.7, 8: 10.3 per batch)
-	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_, int chunk_ = 0)
+	int seed_bwd_batch = getenv("ARX_SEED_BWD_BATCH") ? atoi(getenv("ARX_SEED_BWD_BATCH")) : 0; // 0: seed_batch
+	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_, int chunk_ = 0, int batch_ = 0)
 	{
 		if (chunk_ <= 0) chunk_ = seed_chunk;
+		if (batch_ <= 0) batch_ = seed_batch;
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
 		int blocks = (n + 63) / 64; if (blocks > n_cu * bpc_) blocks = n_cu * bpc_;
-		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, seed_batch, chunk_);
+		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, batch_, chunk_);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *counter)
@@ -276,7 +278,7 @@ struct HipRT {
 		int32_t *heavy = alloc<int32_t>((size_t)n + 2);
 		memset0(heavy + n, 4);
 		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row};
-		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, seed_bpc, seed_bwd_chunk);
+		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, seed_bpc, seed_bwd_chunk, seed_bwd_batch);
 		if (seed_bwd_budget > 0) {
 			Scope sc(*this, "seed_bwd_wave", n);
 			hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
