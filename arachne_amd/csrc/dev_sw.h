@@ -339,11 +339,12 @@ ARX_DEV bool gen_cigar2(const IndexView &ix, int w_, const uint8_t *query, int q
 	if (re > L << 1 || rb < 0) return false; // bns_get_seq would clip: "re - rb != rlen" (bwa.c:134)
 	const int rlen = (int)(re - rb);
 	SegView sv{query, qb, qe, rb, re, rb >= L};
-	if (l_query == rlen && w_ == 0) { // gap-free shortcut (bwa.c:141-149)
-		int s = 0;
-		for (int i = 0; i < l_query; ++i) s += sc_mat(sv.tat(ix, i), sv.qat(i));
+	if (l_query == rlen && w_ == 0) { // gap-free shortcut (bwa.c:141-149); NM of the single M run (bwa.c:169-199) in the same walk
+		int s = 0, n_mm = 0;
+		for (int i = 0; i < l_query; ++i) { const int t = sv.tat(ix, i), q = sv.qat(i); s += sc_mat(t, q); n_mm += q != t; }
 		*score = s;
-		if (want_cigar) { cg[0] = (uint32_t)l_query << 4; *n_cigar = 1; }
+		if (want_cigar) { cg[0] = (uint32_t)l_query << 4; *n_cigar = 1; if (cap >= 1) *NM = n_mm; }
+		return true;
 	} else {
 		int max_gap = ((l_query + 1) >> 1) - 5; // max_ins == max_del with o=6, e=1, a=1
 		max_gap = max_gap > 1 ? max_gap : 1;
