@@ -140,8 +140,18 @@ def test_missing_file_is_an_error(lib):
 def test_fastq_to_placements_hostsim(built):
     """End to end on the host test double: FASTQ -> feeder -> batch -> RFA gives what the arrays it was written from give."""
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    _fastq_to_placements(SIM, 4, 60)
+
+
+@pytest.mark.gpu
+def test_fastq_to_placements_gpu(built):
+    """The same through libarachne_amd.so on the GPU, gzip input, two super-batches."""
+    _fastq_to_placements(api.LIB_PATH, 12, 400, gz=True, target=3000)
+
+
+def _fastq_to_placements(SIM, n_bc, ppb, gz=False, target=10**6):
     g = synth.make_genome(5, [300000, 100000])
-    rs = synth.make_reads(6, g, 4, 60)
+    rs = synth.make_reads(6, g, n_bc, ppb)
     d = tempfile.mkdtemp(prefix="arx_feed_")
     fa = os.path.join(d, "g.fa")
     g.write_fasta(fa)
@@ -154,17 +164,29 @@ def test_fastq_to_placements_hostsim(built):
             for side, out in ((0, r1), (1, r2)):
                 s = "".join(ACGT[x] for x in rs.seqs[2 * p + side][:rs.lens[2 * p + side]])
                 out.append(f"@p{p}/{side + 1} BX:Z:{rs.barcodes[b]} VX:i:1\n{s}\n+\n{'I' * len(s)}\n")
-    fd = api.Feeder(_write(d, "r1.fq", "".join(r1)), _write(d, "r2.fq", "".join(r2)), lib_path=SIM)
-    sb = fd.next(10**6)
-    assert fd.next(1) is None
-    assert (sb["set_pair_off"] == po).all() and sb["barcodes"] == list(rs.barcodes)
+    ext = ".fq.gz" if gz else ".fq"
+    fd = api.Feeder(_write(d, "r1" + ext, "".join(r1), gz=gz), _write(d, "r2" + ext, "".join(r2), gz=gz), lib_path=SIM)
     ref = api.Reference(fa, lib_path=SIM)
     flags = [api.worth_running_rfa(rs.barcodes[b], int(po[b + 1] - po[b])) for b in range(len(po) - 1)]
-    assert list(sb["do_rfa"]) == [int(x) for x in flags]
-    a = ref.batch(sb["bases"], sb["lens"]).run()
-    b = ref.batch(rs.seqs, rs.lens).run()
-    ca, cb = a.rfa(sb["set_pair_off"], sb["do_rfa"]), b.rfa(po, flags)
-    assert (ca["cand_off"] == cb["cand_off"]).all() and ca["cands"].tobytes() == cb["cands"].tobytes()
-    a.free()
-    b.free()
+    s0 = 0                                         # barcode sets consumed so far
+    n_batches = 0
+    while True:
+        sb = fd.next(target)
+        if sb is None:
+            break
+        n_batches += 1
+        s1 = s0 + sb["n_sets"]
+        assert (sb["set_pair_off"] == po[s0:s1 + 1] - po[s0]).all() and sb["barcodes"] == list(rs.barcodes[s0:s1])
+        assert list(sb["do_rfa"]) == [int(x) for x in flags[s0:s1]]
+        p0, p1 = int(po[s0]), int(po[s1])
+        a = ref.batch(sb["bases"], sb["lens"]).run()
+        b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1]).run()
+        ca, cb = a.rfa(sb["set_pair_off"], sb["do_rfa"]), b.rfa(po[s0:s1 + 1] - po[s0], flags[s0:s1])
+        assert (ca["cand_off"] == cb["cand_off"]).all() and ca["cands"].tobytes() == cb["cands"].tobytes()
+        pa, pb = a.post(), b.post()
+        assert pa["post"].tobytes() == pb["post"].tobytes() and pa["split"].tobytes() == pb["split"].tobytes()
+        a.free()
+        b.free()
+        s0 = s1
+    assert s0 == len(po) - 1 and n_batches >= (2 if target < rs.n_pairs else 1)
     ref.close()
