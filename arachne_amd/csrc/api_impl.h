@@ -30,6 +30,11 @@ struct KSaDense {
 	ARX_DEV void operator()(int i, int) const { out[i] = sa_lookup(ix, (uint64_t)i * (uint64_t)d); }
 };
 
+struct KOccRepack { // BWA's block layout -> the checkpointed one (dev_fm.h), one thread per 64-byte block
+	uint32_t *bwt;
+	ARX_DEV void operator()(int i, int) const { occ_repack_block(bwt + (size_t)i * 16); }
+};
+
 template <class RT> struct Context {
 	RT rt;                      // index uploads
 	int device = 0;
@@ -53,14 +58,20 @@ template <class RT> struct Context {
 		e = load_index(prefix, hix);
 		if (!e.empty()) return e;
 		auto up = [&](const void *src, size_t bytes) { void *d = rt.template palloc<uint8_t>(bytes + 64); rt.h2d(d, src, bytes); dev_index.push_back(d); return d; };
-		{ // the Occ blocks go to HBM in the checkpointed layout of dev_fm.h (the files keep BWA's)
-			std::vector<uint32_t> packed(hix.bwt);
-			packed.resize((packed.size() + 15) / 16 * 16, 0);
-			for (size_t b = 0; b + 16 <= packed.size(); b += 16) occ_repack_block(packed.data() + b);
-			ix.bwt = (const uint32_t *)up(packed.data(), packed.size() * 4);
+		{ // the Occ blocks go to HBM in the checkpointed layout of dev_fm.h (the files keep BWA's): uploaded as they are, re-packed in place
+			const size_t n_blk = hix.bwt.size() / 16;
+			if (n_blk >= 0x7fffffffull) return "index too large: more than 2^31 Occ blocks";
+			uint32_t *d = (uint32_t *)up(hix.bwt.data(), hix.bwt.size() * 4);
+			std::vector<uint32_t>().swap(hix.bwt);
+			KOccRepack kr{d};
+			rt.launch_wide("occ_repack", (int)n_blk, kr);
+			rt.sync();
+			ix.bwt = d;
 		}
 		ix.sa = (const uint64_t *)up(hix.sa.data(), hix.sa.size() * 8);
+		std::vector<uint64_t>().swap(hix.sa);
 		ix.pac = (const uint8_t *)up(hix.pac.data(), hix.pac.size());
+		std::vector<uint8_t>().swap(hix.pac);
 		ix.ann_off = (const int64_t *)up(hix.ann_off.data(), hix.ann_off.size() * 8);
 		ix.ann_len = (const int32_t *)up(hix.ann_len.data(), hix.ann_len.size() * 4);
 		ix.ann_alt = (const int32_t *)up(hix.ann_alt.data(), hix.ann_alt.size() * 4);
@@ -129,7 +140,7 @@ template <class RT> struct Batch {
 	int arx_index_build(const char *fasta, const char *prefix, char *msg, int32_t msg_cap)                                          \
 	{                                                                                                                               \
 		std::string e;                                                                                                              \
-		try { e = arx::build_index(fasta, prefix); } catch (const std::exception &ex) { e = ex.what(); }                            \
+		try { e = arx::build_index(fasta, prefix, RT::bwt_sa_fn()); } catch (const std::exception &ex) { e = ex.what(); }                            \
 		if (msg && msg_cap > 0) snprintf(msg, msg_cap, "%s", e.c_str());                                                            \
 		return e.empty() ? ARX_OK : ARX_E_OPEN;                                                                                     \
 	}                                                                                                                               \

@@ -14,6 +14,7 @@
 #include "hip_block.h"
 #include "hip_nw_coop.h"
 #include "hip_fm_coop.h"
+#include "index_build.h"
 
 namespace arx {
 
@@ -37,8 +38,11 @@ struct CastI64 { __host__ __device__ int64_t operator()(const int32_t &x) const 
 
 struct KernelTimer { double ms = 0; int64_t calls = 0, items = 0; };
 
+std::string product_bwt_sa(const uint8_t *pac, size_t pac_bytes, int64_t l_pac, const uint64_t cnt_fwd[4], const std::string &prefix); // arx_index.hip
+
 struct HipRT {
 	static const char *name() { return "hip:gfx950"; }
+	static BwtSaFn bwt_sa_fn() { return product_bwt_sa; } // arx_index_build: the suffix sort runs in HBM
 	hipStream_t stream = 0;
 	int n_cu = 256;
 	bool timing = false;

@@ -4,8 +4,9 @@
 // <prefix>.sa (bwt.c:62-84 bwt_cal_sa, :397-407 bwt_dump_sa).
 //
 // The BWT of a text is unique, so instead of the reference's two construction algorithms (IS for < 50 Mbp, ropes
-// above) one linear-time suffix sorter (induced sorting, written from scratch below) serves every size; the sampled
-// SA is read straight off the suffix array instead of being recovered by n LF steps.
+// above) any suffix sorter gives its bytes: induced sorting on the host below (32-bit, for builds without a GPU), prefix
+// doubling in HBM in hip_index_build.h (what libarachne_amd.so uses when a device is visible; GRCh38-size genomes); the
+// sampled SA is read straight off the suffix array instead of being recovered by n LF steps.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -107,104 +108,23 @@ static const unsigned char kNt4[256] = { // nst_nt4_table (bntseq.c:47-64): A/C/
 #undef R16
 };
 
-// Build all index files from a plain-text FASTA.  Returns "" or an error message.
-inline std::string build_index(const std::string &fasta, const std::string &prefix, BuildStats *stats = nullptr)
+// The step that turns the packed forward strand into <prefix>.bwt and <prefix>.sa: on the host below (induced sorting, 32-bit:
+// 2 * l_pac < 2^31), on the device in hip_index_build.h (any size the HBM holds).  Returns "" or an error message.
+typedef std::string (*BwtSaFn)(const uint8_t *pac, size_t pac_bytes, int64_t l_pac, const uint64_t cnt_fwd[4], const std::string &prefix);
+
+inline std::string build_bwt_sa_host(const uint8_t *pac, size_t, int64_t l_pac, const uint64_t cnt_fwd[4], const std::string &prefix)
 {
-	FILE *f = fopen(fasta.c_str(), "rb");
-	if (!f) return "cannot open " + fasta;
-	struct Ann { std::string name, anno; int64_t offset; int32_t len, n_ambs; };
-	struct Amb { int64_t offset; int32_t len; char amb; };
-	std::vector<Ann> anns;
-	std::vector<Amb> ambs;
-	std::vector<uint8_t> fwd; // one code per base, N already randomised
-	Rand48 rng(11);
-	{
-		std::vector<char> buf(1 << 20);
-		std::string line;
-		int lasts = 0;
-		bool in_hdr = false;
-		std::string hdr;
-		auto start_seq = [&](const std::string &h) {
-			Ann a; size_t i = 0;
-			while (i < h.size() && h[i] != ' ' && h[i] != '\t') ++i;
-			a.name = h.substr(0, i);
-			while (i < h.size() && (h[i] == ' ' || h[i] == '\t')) ++i;
-			a.anno = i < h.size() ? h.substr(i) : "(null)";
-			a.offset = (int64_t)fwd.size(); a.len = 0; a.n_ambs = 0;
-			anns.push_back(a);
-			lasts = 0;
-		};
-		size_t got;
-		while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
-			for (size_t k = 0; k < got; ++k) {
-				char ch = buf[k];
-				if (in_hdr) {
-					if (ch == '\n') { in_hdr = false; while (!hdr.empty() && hdr.back() == '\r') hdr.pop_back(); start_seq(hdr); hdr.clear(); }
-					else hdr.push_back(ch);
-					continue;
-				}
-				if (ch == '>') { in_hdr = true; continue; }
-				if (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t') continue;
-				if (anns.empty()) { fclose(f); return "FASTA does not start with '>'"; }
-				Ann &a = anns.back();
-				int c = kNt4[(unsigned char)ch];
-				if (c >= 4) { // runs of the same ambiguous character form one hole (bntseq.c:245-259)
-					if (lasts == ch) ++ambs.back().len;
-					else { ambs.push_back(Amb{a.offset + a.len, 1, ch}); ++a.n_ambs; }
-					c = rng.lrand() & 3;
-				}
-				lasts = ch;
-				fwd.push_back((uint8_t)c);
-				++a.len;
-			}
-		}
-		fclose(f);
-	}
-	const int64_t l_pac = (int64_t)fwd.size();
-	if (l_pac == 0) return "empty FASTA";
-	if (stats) { stats->l_pac = l_pac; stats->n_seqs = (int)anns.size(); stats->n_holes = (int)ambs.size(); }
-	// .pac: forward strand only, (l_pac/4 + 1 + 1) bytes; the last byte is l_pac % 4 (bntseq.c:306-319)
-	{
-		std::vector<uint8_t> pac((size_t)(l_pac >> 2) + ((l_pac & 3) ? 1 : 0), 0);
-		for (int64_t l = 0; l < l_pac; ++l) pac[l >> 2] |= fwd[l] << ((~l & 3) << 1);
-		FILE *o = fopen((prefix + ".pac").c_str(), "wb");
-		if (!o) return "cannot write " + prefix + ".pac";
-		fwrite(pac.data(), 1, pac.size(), o);
-		uint8_t ct = 0;
-		if (l_pac % 4 == 0) fwrite(&ct, 1, 1, o);
-		ct = (uint8_t)(l_pac % 4);
-		fwrite(&ct, 1, 1, o);
-		fclose(o);
-	}
-	{
-		FILE *o = fopen((prefix + ".ann").c_str(), "w");
-		if (!o) return "cannot write " + prefix + ".ann";
-		fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)anns.size(), 11u);
-		for (auto &a : anns) {
-			fprintf(o, "%d %s", 0, a.name.c_str());
-			if (!a.anno.empty()) fprintf(o, " %s\n", a.anno.c_str()); else fprintf(o, "\n");
-			fprintf(o, "%lld %d %d\n", (long long)a.offset, a.len, a.n_ambs);
-		}
-		fclose(o);
-		o = fopen((prefix + ".amb").c_str(), "w");
-		if (!o) return "cannot write " + prefix + ".amb";
-		fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)anns.size(), (unsigned)ambs.size());
-		for (auto &h : ambs) fprintf(o, "%lld %d %c\n", (long long)h.offset, h.len, h.amb);
-		fclose(o);
-	}
 	// text = forward + reverse complement (bntseq.c:299-305), symbols shifted by one to make room for the sentinel
 	const int64_t n = 2 * l_pac;
-	if (n + 1 >= ((int64_t)1 << 31)) return "genome too large for the 32-bit suffix sorter of this build (2*l_pac must stay below 2^31)";
+	if (n + 1 >= ((int64_t)1 << 31)) return "genome too large for the host suffix sorter (2*l_pac must stay below 2^31): the device builder of libarachne_amd.so has no such limit, but needs an MI355X";
 	std::vector<uint8_t> text((size_t)n + 1);
-	for (int64_t i = 0; i < l_pac; ++i) { text[i] = fwd[i] + 1; text[n - 1 - i] = (3 - fwd[i]) + 1; }
+	for (int64_t i = 0; i < l_pac; ++i) { const int c = pac[i >> 2] >> ((~i & 3) << 1) & 3; text[i] = c + 1; text[n - 1 - i] = (3 - c) + 1; }
 	text[n] = 0;
-	std::vector<uint8_t>().swap(fwd);
 	std::vector<int32_t> SA((size_t)n + 1);
 	SaIs<uint8_t, int32_t>::run(text.data(), SA.data(), (int32_t)(n + 1), 5);
 	// BWT without the $ row, primary = rank of suffix 0 (is.c:208-223 is_bwt)
 	uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0};
-	for (int64_t i = 0; i < n; ++i) ++L2[text[i]]; // text[i] in 1..4 -> counts land in L2[1..4]
-	for (int c = 2; c <= 4; ++c) L2[c] += L2[c - 1];
+	for (int c = 0; c < 4; ++c) L2[c + 1] = L2[c] + cnt_fwd[c] + cnt_fwd[3 - c];
 	std::vector<uint8_t> bw((size_t)n);
 	{
 		int64_t k = 0;
@@ -243,6 +163,102 @@ inline std::string build_index(const std::string &fasta, const std::string &pref
 		fclose(o);
 	}
 	return "";
+}
+
+// Build all index files from a plain-text FASTA.  Returns "" or an error message.
+inline std::string build_index(const std::string &fasta, const std::string &prefix, BwtSaFn bwt_sa = build_bwt_sa_host, BuildStats *stats = nullptr)
+{
+	FILE *f = fopen(fasta.c_str(), "rb");
+	if (!f) return "cannot open " + fasta;
+	struct Ann { std::string name, anno; int64_t offset; int32_t len, n_ambs; };
+	struct Amb { int64_t offset; int32_t len; char amb; };
+	std::vector<Ann> anns;
+	std::vector<Amb> ambs;
+	std::vector<uint8_t> pac; // forward strand, 4 bases per byte (first base in the top bits), N already randomised
+	int64_t l_pac = 0;
+	uint64_t cnt_fwd[4] = {0, 0, 0, 0};
+	Rand48 rng(11);
+	{
+		fseek(f, 0, SEEK_END);
+		const long fsz = ftell(f);
+		fseek(f, 0, SEEK_SET);
+		if (fsz > 0) pac.reserve((size_t)fsz / 4 + 64);
+		std::vector<char> buf(1 << 22);
+		int lasts = 0;
+		bool in_hdr = false;
+		std::string hdr;
+		uint8_t acc = 0; // the byte being filled
+		auto start_seq = [&](const std::string &h) {
+			Ann a; size_t i = 0;
+			while (i < h.size() && h[i] != ' ' && h[i] != '\t') ++i;
+			a.name = h.substr(0, i);
+			while (i < h.size() && (h[i] == ' ' || h[i] == '\t')) ++i;
+			a.anno = i < h.size() ? h.substr(i) : "(null)";
+			a.offset = l_pac; a.len = 0; a.n_ambs = 0;
+			anns.push_back(a);
+			lasts = 0;
+		};
+		size_t got;
+		while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
+			for (size_t k = 0; k < got; ++k) {
+				const char ch = buf[k];
+				if (in_hdr) {
+					if (ch == '\n') { in_hdr = false; while (!hdr.empty() && hdr.back() == '\r') hdr.pop_back(); start_seq(hdr); hdr.clear(); }
+					else hdr.push_back(ch);
+					continue;
+				}
+				if (ch == '>') { in_hdr = true; continue; }
+				if (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t') continue;
+				if (anns.empty()) { fclose(f); return "FASTA does not start with '>'"; }
+				Ann &a = anns.back();
+				int c = kNt4[(unsigned char)ch];
+				if (c >= 4) { // runs of the same ambiguous character form one hole (bntseq.c:245-259)
+					if (lasts == ch) ++ambs.back().len;
+					else { ambs.push_back(Amb{a.offset + a.len, 1, ch}); ++a.n_ambs; }
+					c = rng.lrand() & 3;
+				}
+				lasts = ch;
+				acc |= (uint8_t)(c << ((~l_pac & 3) << 1));
+				if ((l_pac & 3) == 3) { pac.push_back(acc); acc = 0; }
+				++cnt_fwd[c];
+				++l_pac;
+				++a.len;
+			}
+		}
+		if (l_pac & 3) pac.push_back(acc);
+		fclose(f);
+	}
+	if (l_pac == 0) return "empty FASTA";
+	if (stats) { stats->l_pac = l_pac; stats->n_seqs = (int)anns.size(); stats->n_holes = (int)ambs.size(); }
+	// .pac: forward strand only, (l_pac/4 + 1 + 1) bytes; the last byte is l_pac % 4 (bntseq.c:306-319)
+	{
+		FILE *o = fopen((prefix + ".pac").c_str(), "wb");
+		if (!o) return "cannot write " + prefix + ".pac";
+		fwrite(pac.data(), 1, pac.size(), o);
+		uint8_t ct = 0;
+		if (l_pac % 4 == 0) fwrite(&ct, 1, 1, o);
+		ct = (uint8_t)(l_pac % 4);
+		fwrite(&ct, 1, 1, o);
+		fclose(o);
+	}
+	{
+		FILE *o = fopen((prefix + ".ann").c_str(), "w");
+		if (!o) return "cannot write " + prefix + ".ann";
+		fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)anns.size(), 11u);
+		for (auto &a : anns) {
+			fprintf(o, "%d %s", 0, a.name.c_str());
+			if (!a.anno.empty()) fprintf(o, " %s\n", a.anno.c_str()); else fprintf(o, "\n");
+			fprintf(o, "%lld %d %d\n", (long long)a.offset, a.len, a.n_ambs);
+		}
+		fclose(o);
+		o = fopen((prefix + ".amb").c_str(), "w");
+		if (!o) return "cannot write " + prefix + ".amb";
+		fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)anns.size(), (unsigned)ambs.size());
+		for (auto &h : ambs) fprintf(o, "%lld %d %c\n", (long long)h.offset, h.len, h.amb);
+		fclose(o);
+	}
+	pac.resize(pac.size() + 16, 0); // readers below may look a few bytes past the end
+	return bwt_sa(pac.data(), pac.size() - 16, l_pac, cnt_fwd, prefix);
 }
 
 } // namespace arx

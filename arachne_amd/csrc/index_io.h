@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -20,42 +21,48 @@ struct HostIndex {
 	std::vector<int32_t> ann_len, ann_alt;
 };
 
-inline bool read_all(const std::string &fn, std::vector<uint8_t> &buf)
-{
-	FILE *f = fopen(fn.c_str(), "rb");
-	if (!f) return false;
-	fseek(f, 0, SEEK_END);
-	long sz = ftell(f);
-	fseek(f, 0, SEEK_SET);
-	buf.resize(sz);
-	bool ok = sz == 0 || fread(buf.data(), 1, sz, f) == (size_t)sz;
-	fclose(f);
-	return ok;
-}
+inline int64_t file_size(FILE *f) { fseeko(f, 0, SEEK_END); int64_t sz = (int64_t)ftello(f); fseeko(f, 0, SEEK_SET); return sz; }
 
 // returns "" on success, else a message
 inline std::string load_index(const std::string &prefix, HostIndex &ix)
 {
-	std::vector<uint8_t> raw;
-	if (!read_all(prefix + ".bwt", raw) || raw.size() < 40) return "cannot read " + prefix + ".bwt";
-	memcpy(&ix.primary, raw.data(), 8);
-	memcpy(&ix.L2[1], raw.data() + 8, 32);
-	ix.L2[0] = 0;
-	ix.seq_len = ix.L2[4];
-	size_t n_words = (raw.size() - 40) / 4;
-	ix.bwt.assign(((n_words + 15) / 16 + 1) * 16, 0);
-	memcpy(ix.bwt.data(), raw.data() + 40, n_words * 4);
-	if (!read_all(prefix + ".sa", raw) || raw.size() < 56) return "cannot read " + prefix + ".sa";
-	uint64_t prim, sintv, slen;
-	memcpy(&prim, raw.data(), 8); memcpy(&sintv, raw.data() + 40, 8); memcpy(&slen, raw.data() + 48, 8);
-	if (prim != ix.primary || slen != ix.seq_len) return "SA-BWT inconsistency in " + prefix + ".sa";
-	if (sintv == 0 || (sintv & (sintv - 1))) return "SA interval is not a power of two";
-	ix.sa_intv = (int)sintv;
-	uint64_t n_sa = (ix.seq_len + sintv) / sintv;
-	if (raw.size() < 56 + (n_sa - 1) * 8) return "truncated " + prefix + ".sa";
-	ix.sa.assign(n_sa, 0);
-	ix.sa[0] = (uint64_t)-1;
-	memcpy(ix.sa.data() + 1, raw.data() + 56, (n_sa - 1) * 8);
+	{ // .bwt: u64 primary, 4 x u64 L2[1..4], then the interleaved Occ/BWT words (bwt.c:443-462), read straight into place
+		FILE *fb = fopen((prefix + ".bwt").c_str(), "rb");
+		if (!fb) return "cannot read " + prefix + ".bwt";
+		const int64_t sz = file_size(fb);
+		uint64_t head[5];
+		if (sz < 40 || fread(head, 8, 5, fb) != 5) { fclose(fb); return "cannot read " + prefix + ".bwt"; }
+		ix.primary = head[0];
+		ix.L2[0] = 0;
+		for (int c = 0; c < 4; ++c) ix.L2[c + 1] = head[c + 1];
+		ix.seq_len = ix.L2[4];
+		const size_t n_words = (size_t)(sz - 40) / 4;
+		// a truncated or foreign file would send the device past the end of the table (bwt_size of bwtindex.c:151-173)
+		const uint64_t want = ((ix.seq_len + 15) >> 4) + ((ix.seq_len + 127) / 128 + 1) * 8;
+		if ((uint64_t)n_words != want || (sz - 40) % 4) { fclose(fb); return prefix + ".bwt does not hold the " + std::to_string(want) + " words its header announces"; }
+		ix.bwt.assign(((n_words + 15) / 16 + 1) * 16, 0);
+		const bool ok = fread(ix.bwt.data(), 4, n_words, fb) == n_words;
+		fclose(fb);
+		if (!ok) return "cannot read " + prefix + ".bwt";
+	}
+	{ // .sa: primary, 4 x u64 skipped, interval, seq_len, then sa[1..] (bwt.c:421-441)
+		FILE *fs = fopen((prefix + ".sa").c_str(), "rb");
+		if (!fs) return "cannot read " + prefix + ".sa";
+		const int64_t sz = file_size(fs);
+		uint64_t head[7];
+		if (sz < 56 || fread(head, 8, 7, fs) != 7) { fclose(fs); return "cannot read " + prefix + ".sa"; }
+		const uint64_t prim = head[0], sintv = head[5], slen = head[6];
+		if (prim != ix.primary || slen != ix.seq_len) { fclose(fs); return "SA-BWT inconsistency in " + prefix + ".sa"; }
+		if (sintv == 0 || (sintv & (sintv - 1))) { fclose(fs); return "SA interval is not a power of two"; }
+		ix.sa_intv = (int)sintv;
+		const uint64_t n_sa = (ix.seq_len + sintv) / sintv;
+		if ((uint64_t)sz < 56 + (n_sa - 1) * 8) { fclose(fs); return "truncated " + prefix + ".sa"; }
+		ix.sa.assign(n_sa, 0);
+		ix.sa[0] = (uint64_t)-1;
+		const bool ok = n_sa < 2 || fread(ix.sa.data() + 1, 8, n_sa - 1, fs) == n_sa - 1;
+		fclose(fs);
+		if (!ok) return "cannot read " + prefix + ".sa";
+	}
 	FILE *f = fopen((prefix + ".ann").c_str(), "r");
 	if (!f) return "cannot read " + prefix + ".ann";
 	long long lp; int ns; unsigned seed;
@@ -81,9 +88,15 @@ inline std::string load_index(const std::string &prefix, HostIndex &ix)
 		}
 		fclose(f);
 	}
-	if (!read_all(prefix + ".pac", raw) || (int64_t)raw.size() < ix.l_pac / 4 + 1) return "cannot read " + prefix + ".pac";
-	ix.pac.assign(raw.begin(), raw.begin() + ix.l_pac / 4 + 1);
-	ix.pac.resize(ix.pac.size() + 16, 0);
+	{
+		FILE *fp = fopen((prefix + ".pac").c_str(), "rb");
+		if (!fp) return "cannot read " + prefix + ".pac";
+		const size_t want = (size_t)(ix.l_pac / 4 + 1);
+		ix.pac.assign(want + 16, 0);
+		const bool ok = fread(ix.pac.data(), 1, want, fp) == want;
+		fclose(fp);
+		if (!ok) return "cannot read " + prefix + ".pac";
+	}
 	return "";
 }
 

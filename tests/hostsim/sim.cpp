@@ -64,6 +64,7 @@ static int sim_rescue_check_f() { const char *e = getenv("ARX_RESCUE_CHECK"); re
 		const int m2_ = sort_dedup_patch(ix, 0, (int)chk_.size(), chk_.data(), t_.data(), i_.data(), 0); \
 		if (m2_ != (m) || memcmp(chk_.data(), (ma), sizeof(Reg) * (size_t)m2_)) { fprintf(stderr, "[sim] dedup_insert differs from mem_sort_dedup_patch: %d vs %d regions\n", (m), m2_); abort(); } } } while (0)
 #include "../../arachne_amd/csrc/arx_dev.h"
+#include "../../arachne_amd/csrc/index_build.h"
 
 #include <algorithm>
 namespace arx {
@@ -100,6 +101,7 @@ struct SimBlock {
 struct KernelTimer { double ms = 0; int64_t calls = 0, items = 0; };
 struct SimRT {
 	static const char *name() { return "hostsim"; }
+	static arx::BwtSaFn bwt_sa_fn() { return arx::build_bwt_sa_host; }
 	std::map<std::string, KernelTimer> tm;
 	std::string init(int) { return ""; }
 	void bind() {}
