@@ -47,7 +47,15 @@ struct DevBuf {
 	DevBuf() {}
 	explicit DevBuf(size_t b) { alloc(b); }
 	DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
-	void alloc(size_t b) { release(); bytes = b ? b : 8; ARX_IDX_CHECK(hipMalloc(&p, bytes)); }
+	void alloc(size_t b)
+	{
+		release(); bytes = b ? b : 8;
+		if (hipMalloc(&p, bytes) != hipSuccess) {
+			size_t fr = 0, to = 0; (void)hipMemGetInfo(&fr, &to);
+			p = nullptr;
+			throw std::runtime_error("index build: out of device memory (wanted " + std::to_string(bytes >> 20) + " MiB, " + std::to_string(fr >> 20) + " of " + std::to_string(to >> 20) + " MiB free)");
+		}
+	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 	~DevBuf() { release(); }
 	template <class T> T *as() const { return (T *)p; }
@@ -57,8 +65,11 @@ typedef unsigned long long u64;
 constexpr int BUCKET_BASES = 12;
 constexpr u64 N_BUCKETS = 1ull << (2 * BUCKET_BASES);
 
+// A dispatch holds fewer than 2^32 work-items (the AQL packet's grid size is 32-bit) and GRCh38 has 6.2 G suffixes: every kernel is a
+// grid-stride loop over at most 2^30 lanes.
 __device__ __forceinline__ u64 gid() { return (u64)blockIdx.x * blockDim.x + threadIdx.x; }
-inline dim3 grid_for(u64 n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+#define ARX_GRID_LOOP(i, n) for (u64 i = gid(), stride_ = (u64)gridDim.x * blockDim.x; i < (n); i += stride_)
+inline dim3 grid_for(u64 n, int block = 256) { u64 b = (n + block - 1) / block; if (b > ((u64)1 << 22)) b = (u64)1 << 22; if (b < 1) b = 1; return dim3((unsigned)b); }
 
 // 32 bases from position i; beyond the text the words are zero ('A')
 __device__ __forceinline__ u64 kmer32(const u64 *T, u64 i)
@@ -74,133 +85,120 @@ __device__ __forceinline__ int base_at(const u64 *T, u64 i) { return (int)(T[i >
 // T[i] = fwd[i] for i < l_pac, 3 - fwd[n - 1 - i] above (bntseq.c:299-305 via bwtindex.c:78-85)
 __global__ void k_pack_text(const uint8_t *pac, u64 l_pac, u64 *T, u64 n_words)
 {
-	const u64 j = gid();
-	if (j >= n_words) return;
 	const u64 n = 2 * l_pac;
-	u64 w = 0;
-	for (int s = 0; s < 32; ++s) {
-		const u64 i = 32 * j + s;
-		int c = 0;
-		if (i < l_pac) c = pac[i >> 2] >> ((~i & 3) << 1) & 3;
-		else if (i < n) { const u64 m = n - 1 - i; c = 3 - (pac[m >> 2] >> ((~m & 3) << 1) & 3); }
-		w |= (u64)c << (62 - 2 * s);
+	ARX_GRID_LOOP(j, n_words) {
+		u64 w = 0;
+		for (int s = 0; s < 32; ++s) {
+			const u64 i = 32 * j + s;
+			int c = 0;
+			if (i < l_pac) c = pac[i >> 2] >> ((~i & 3) << 1) & 3;
+			else if (i < n) { const u64 m = n - 1 - i; c = 3 - (pac[m >> 2] >> ((~m & 3) << 1) & 3); }
+			w |= (u64)c << (62 - 2 * s);
+		}
+		T[j] = w;
 	}
-	T[j] = w;
 }
 
 __global__ void k_hist(const u64 *T, u64 n, u64 *hist)
 {
-	const u64 i = gid();
-	if (i >= n) return;
-	atomicAdd(&hist[kmer32(T, i) >> (64 - 2 * BUCKET_BASES)], 1ull);
+	ARX_GRID_LOOP(i, n) atomicAdd(&hist[kmer32(T, i) >> (64 - 2 * BUCKET_BASES)], 1ull);
 }
 __global__ void k_scatter(const u64 *T, u64 n, u64 *cursor, u64 *SA)
 {
-	const u64 i = gid();
-	if (i >= n) return;
-	SA[atomicAdd(&cursor[kmer32(T, i) >> (64 - 2 * BUCKET_BASES)], 1ull)] = i;
+	ARX_GRID_LOOP(i, n) SA[atomicAdd(&cursor[kmer32(T, i) >> (64 - 2 * BUCKET_BASES)], 1ull)] = i;
 }
 __global__ void k_keys(const u64 *T, const u64 *sa, u64 cnt, u64 *keys)
 {
-	const u64 t = gid();
-	if (t < cnt) keys[t] = kmer32(T, sa[t]);
+	ARX_GRID_LOOP(t, cnt) keys[t] = kmer32(T, sa[t]);
 }
 // hv[t] = global index + 1 of t if it starts a group, else 0 (an inclusive max-scan turns it into the rank of every element)
 __global__ void k_heads(const u64 *keys, u64 cnt, u64 base, u64 *hv)
 {
-	const u64 t = gid();
-	if (t < cnt) hv[t] = (t == 0 || keys[t] != keys[t - 1]) ? base + t + 1 : 0;
+	ARX_GRID_LOOP(t, cnt) hv[t] = (t == 0 || keys[t] != keys[t - 1]) ? base + t + 1 : 0;
 }
 // after the chunk sort: rank and SA go to their arrays; flag = the element shares its group with another
 __global__ void k_chunk_apply(const u64 *sa_sorted, const u64 *rank, u64 cnt, u64 base, u64 *SA, u64 *ISA, u64 *flag)
 {
-	const u64 t = gid();
-	if (t >= cnt) return;
-	const u64 s = sa_sorted[t], r = rank[t];
-	SA[base + t] = s; ISA[s] = r;
-	const bool single = r == base + t + 1 && (t + 1 == cnt || rank[t + 1] == base + t + 2);
-	flag[t] = single ? 0 : 1;
+	ARX_GRID_LOOP(t, cnt) {
+		const u64 s = sa_sorted[t], r = rank[t];
+		SA[base + t] = s; ISA[s] = r;
+		const bool single = r == base + t + 1 && (t + 1 == cnt || rank[t + 1] == base + t + 2);
+		flag[t] = single ? 0 : 1;
+	}
 }
 __global__ void k_compact(const u64 *flag, const u64 *off, u64 cnt, u64 base, const u64 *sa_sorted, u64 *u_pos, u64 *u_sa)
 {
-	const u64 t = gid();
-	if (t < cnt && flag[t]) { u_pos[off[t]] = base + t; u_sa[off[t]] = sa_sorted[t]; }
+	ARX_GRID_LOOP(t, cnt) if (flag[t]) { u_pos[off[t]] = base + t; u_sa[off[t]] = sa_sorted[t]; }
 }
 
 // ---- prefix doubling on the work list (u_pos: index into SA, increasing; u_sa: the suffix there)
 __global__ void k_rank_of(const u64 *u_sa, u64 m, const u64 *ISA, u64 *r)
 {
-	const u64 t = gid();
-	if (t < m) r[t] = ISA[u_sa[t]];
+	ARX_GRID_LOOP(t, m) r[t] = ISA[u_sa[t]];
 }
 // bound[k] = first group start at or after k * S (atomic min over the group starts of [k * S, (k + 1) * S))
 __global__ void k_slice_bounds(const u64 *r, u64 m, u64 S, u64 *bound)
 {
-	const u64 t = gid();
-	if (t >= m) return;
-	if (t == 0 || r[t] != r[t - 1]) atomicMin(&bound[t / S], t);
+	ARX_GRID_LOOP(t, m) if (t == 0 || r[t] != r[t - 1]) atomicMin(&bound[t / S], t);
 }
 __global__ void k_head_flags(const u64 *r, u64 cnt, u64 *hf)
 {
-	const u64 t = gid();
-	if (t < cnt) hf[t] = (t == 0 || r[t] != r[t - 1]) ? 1 : 0;
+	ARX_GRID_LOOP(t, cnt) hf[t] = (t == 0 || r[t] != r[t - 1]) ? 1 : 0;
 }
 // key = (group number within the slice) << kb | rank of the suffix h further on, shifted so that positions beyond the text
 // (the further the smaller) stay non-negative: n + x for x >= 0 beyond ranks below rank(n) = 0 -> h - x
 __global__ void k_comp_keys(const u64 *u_sa, const u64 *gnum, u64 cnt, const u64 *ISA, u64 n, u64 h, int kb, u64 *comp)
 {
-	const u64 t = gid();
-	if (t >= cnt) return;
-	const u64 p = u_sa[t] + h;
-	const u64 v = p >= n ? h - (p - n) : h + ISA[p];
-	comp[t] = (gnum[t] - 1) << kb | v;
+	ARX_GRID_LOOP(t, cnt) {
+		const u64 p = u_sa[t] + h;
+		const u64 v = p >= n ? h - (p - n) : h + ISA[p];
+		comp[t] = (gnum[t] - 1) << kb | v;
+	}
 }
 __global__ void k_heads2(const u64 *comp, const u64 *u_pos, u64 cnt, u64 *hv)
 {
-	const u64 t = gid();
-	if (t < cnt) hv[t] = (t == 0 || comp[t] != comp[t - 1]) ? u_pos[t] + 1 : 0;
+	ARX_GRID_LOOP(t, cnt) hv[t] = (t == 0 || comp[t] != comp[t - 1]) ? u_pos[t] + 1 : 0;
 }
 __global__ void k_round_apply(const u64 *sa_sorted, const u64 *rank, const u64 *u_pos, u64 cnt, u64 *SA, u64 *ISA, u64 *flag)
 {
-	const u64 t = gid();
-	if (t >= cnt) return;
-	const u64 s = sa_sorted[t], r = rank[t];
-	ISA[s] = r; SA[u_pos[t]] = s;
-	const bool single = r == u_pos[t] + 1 && (t + 1 == cnt || rank[t + 1] == u_pos[t + 1] + 1);
-	flag[t] = single ? 0 : 1;
+	ARX_GRID_LOOP(t, cnt) {
+		const u64 s = sa_sorted[t], r = rank[t];
+		ISA[s] = r; SA[u_pos[t]] = s;
+		const bool single = r == u_pos[t] + 1 && (t + 1 == cnt || rank[t + 1] == u_pos[t + 1] + 1);
+		flag[t] = single ? 0 : 1;
+	}
 }
 __global__ void k_compact2(const u64 *flag, const u64 *off, u64 cnt, const u64 *u_pos, const u64 *sa_sorted, u64 *o_pos, u64 *o_sa)
 {
-	const u64 t = gid();
-	if (t < cnt && flag[t]) { o_pos[off[t]] = u_pos[t]; o_sa[off[t]] = sa_sorted[t]; }
+	ARX_GRID_LOOP(t, cnt) if (flag[t]) { o_pos[off[t]] = u_pos[t]; o_sa[off[t]] = sa_sorted[t]; }
 }
 
 // ---- emit
 // row r of the full matrix (0..n): suffix n for r = 0, SA[r - 1] otherwise; the BWT string skips the row of suffix 0 (= primary)
 __global__ void k_bwt_words(const u64 *T, const u64 *SA, u64 n, u64 primary, u64 n_words, uint32_t *words, uint32_t *wcnt)
 {
-	const u64 w = gid();
-	if (w >= n_words) return;
-	uint32_t x = 0, c[4] = {0, 0, 0, 0};
-	for (int s = 0; s < 16; ++s) {
-		const u64 k = 16 * w + s;
-		if (k >= n) break;
-		const u64 r = k + (k >= primary);
-		const u64 suf = r == 0 ? n : SA[r - 1];
-		const int b = base_at(T, suf - 1);
-		x |= (uint32_t)b << (30 - 2 * s);
-		++c[b];
+	ARX_GRID_LOOP(w, n_words) {
+		uint32_t x = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+		for (int s = 0; s < 16; ++s) {
+			const u64 k = 16 * w + s;
+			if (k >= n) break;
+			const u64 r = k + (k >= primary);
+			const u64 suf = r == 0 ? n : SA[r - 1];
+			const int b = base_at(T, suf - 1);
+			x |= (uint32_t)b << (30 - 2 * s);
+			c0 += b == 0; c1 += b == 1; c2 += b == 2; c3 += b == 3;
+		}
+		words[w] = x;
+		wcnt[w] = c0 | c1 << 8 | c2 << 16 | c3 << 24;
 	}
-	words[w] = x;
-	wcnt[w] = c[0] | c[1] << 8 | c[2] << 16 | c[3] << 24;
 }
 __global__ void k_block_counts(const uint32_t *wcnt, u64 n_words, u64 n_blocks, u64 *c0, u64 *c1, u64 *c2, u64 *c3)
 {
-	const u64 b = gid();
-	if (b >= n_blocks) return;
-	uint32_t s = 0;
-	for (int j = 0; j < 8; ++j) { const u64 w = 8 * b + j; if (w < n_words) s += wcnt[w]; } // <= 128 per byte lane: no carry
-	c0[b] = s & 0xff; c1[b] = (s >> 8) & 0xff; c2[b] = (s >> 16) & 0xff; c3[b] = s >> 24;
+	ARX_GRID_LOOP(b, n_blocks) {
+		uint32_t s = 0;
+		for (int j = 0; j < 8; ++j) { const u64 w = 8 * b + j; if (w < n_words) s += wcnt[w]; } // <= 128 per byte lane: no carry
+		c0[b] = s & 0xff; c1[b] = (s >> 8) & 0xff; c2[b] = (s >> 16) & 0xff; c3[b] = s >> 24;
+	}
 }
 // the file layout (bwtindex.c:151-173): before every 128 symbols the four running counts as u64, then the 8 words; after the last
 // symbol the totals.  c0..c3 hold the exclusive prefix sums per block; tot[] the totals.
@@ -208,43 +206,43 @@ __device__ __forceinline__ void put_u64(uint32_t *o, u64 v) { o[0] = (uint32_t)v
 __global__ void k_interleave(const uint32_t *words, u64 n_words, u64 n_blocks, const u64 *c0, const u64 *c1, const u64 *c2, const u64 *c3,
                              const u64 *tot, uint32_t *out)
 {
-	const u64 b = gid();
-	if (b > n_blocks) return;
-	if (b == n_blocks) { uint32_t *o = out + 8 * n_blocks + n_words; for (int c = 0; c < 4; ++c) put_u64(o + 2 * c, tot[c]); return; }
-	uint32_t *o = out + 16 * b;
-	put_u64(o, c0[b]); put_u64(o + 2, c1[b]); put_u64(o + 4, c2[b]); put_u64(o + 6, c3[b]);
-	for (int j = 0; j < 8; ++j) { const u64 w = 8 * b + j; if (w < n_words) o[8 + j] = words[w]; }
+	ARX_GRID_LOOP(b, n_blocks + 1) {
+		if (b == n_blocks) { uint32_t *o = out + 8 * n_blocks + n_words; for (int c = 0; c < 4; ++c) put_u64(o + 2 * c, tot[c]); continue; }
+		uint32_t *o = out + 16 * b;
+		put_u64(o, c0[b]); put_u64(o + 2, c1[b]); put_u64(o + 4, c2[b]); put_u64(o + 6, c3[b]);
+		for (int j = 0; j < 8; ++j) { const u64 w = 8 * b + j; if (w < n_words) o[8 + j] = words[w]; }
+	}
 }
 __global__ void k_sa_sample(const u64 *SA, u64 n_sa, u64 intv, u64 *out) // out[i - 1] = row i * intv, i = 1 .. n_sa - 1
 {
-	const u64 i = gid() + 1;
-	if (i < n_sa) out[i - 1] = SA[i * intv - 1];
+	ARX_GRID_LOOP(k, n_sa - 1) { const u64 i = k + 1; out[i - 1] = SA[i * intv - 1]; }
 }
 
 // ---- verification: SA[j - 1] < SA[j] as suffixes of the text ($ at the end is the smallest symbol), and rank is SA's inverse
-__global__ void k_verify(const u64 *T, const u64 *SA, const u64 *ISA, u64 n, u64 *bad)
+__device__ __forceinline__ bool verify_row(const u64 *T, const u64 *SA, const u64 *ISA, u64 n, u64 j) // true: row j is in order
 {
-	const u64 j = gid();
-	if (j >= n) return;
 	const u64 b = SA[j];
-	if (b >= n || ISA[b] != j + 1) { atomicAdd(bad, 1ull); return; }
-	if (j == 0) return;
+	if (b >= n || ISA[b] != j + 1) return false;
+	if (j == 0) return true;
 	const u64 a = SA[j - 1];
-	if (a >= n) return; // counted by its own thread
+	if (a >= n) return true; // counted at its own row
 	for (u64 d = 0;; d += 32) {
 		const u64 ra = n - (a + d), rb = n - (b + d); // bases left in each suffix (> 0 on entry)
 		const u64 ka = kmer32(T, a + d), kb = kmer32(T, b + d);
 		const u64 lim = ra < rb ? ra : rb;
 		if (lim >= 32) {
-			if (ka != kb) { if (ka > kb) atomicAdd(bad, 1ull); return; }
-			if (ra == 32 || rb == 32) { if (lim == 32 && ra > rb) atomicAdd(bad, 1ull); return; } // the shorter one ended: it is the smaller
+			if (ka != kb) return ka < kb;
+			if (lim == 32) return ra < rb; // the one that ends here is the smaller
 			continue;
 		}
 		const u64 mask = ~0ull << (64 - 2 * lim); // lim in 1..31 real bases in both
-		if ((ka & mask) != (kb & mask)) { if ((ka & mask) > (kb & mask)) atomicAdd(bad, 1ull); return; }
-		if (ra > rb) atomicAdd(bad, 1ull); // equal up to the end of the shorter: a must be the shorter one
-		return;
+		if ((ka & mask) != (kb & mask)) return (ka & mask) < (kb & mask);
+		return ra < rb; // equal up to the end of the shorter: a must be the shorter one
 	}
+}
+__global__ void k_verify(const u64 *T, const u64 *SA, const u64 *ISA, u64 n, u64 *bad)
+{
+	ARX_GRID_LOOP(j, n) if (!verify_row(T, SA, ISA, n, j)) atomicAdd(bad, 1ull);
 }
 
 struct MaxOp { __host__ __device__ u64 operator()(const u64 &a, const u64 &b) const { return a > b ? a : b; } };
