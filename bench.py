@@ -3,15 +3,27 @@
 
 A "step" = one pass of the whole per-barcode path (seed -> locate -> chain -> extend -> rescue -> CIGAR -> candidate
 statistics -> RFA joint placement -> MAPQ, i.e. what the reference does per barcode in GetChains + GetAlignments +
-tagBestAlignments .. estimateMapQualities, aligner.go:450-490) over the workload of BASELINE.json configs[1]:
-a chr20-sized synthetic genome (64,444,167 bp) and 1,000 barcodes x 1,000 pairs of 2x150 bp haplotagging-style reads.
-Reads are uploaded to HBM before the timed region; results stay in HBM (PCIe-inclusive numbers: DESIGN.md).
+tagBestAlignments .. estimateMapQualities, aligner.go:450-490) over one slice of the workload the metric is quoted on:
+
+  --workload grch38 (default)  BASELINE.json configs[2] on one GPU: a GRCh38-size synthetic genome (24 contigs with the lengths of
+                               chr1..22, X, Y: 3,088,269,832 bp, planted repeat families; FM-index 3.1 GB Occ/BWT + 6.2 GB SA
+                               sample in HBM, i.e. far outside the 256 MiB Infinity Cache) and a 1,001,000-pair slice per step of
+                               TELLseq-like 2x150 bp reads (13,000 barcodes x 77 pairs = the 310 M pairs / 4 M barcodes of the
+                               30x set; three device batches in flight).  The index is built by the product itself (arx_index_build: suffix
+                               sorting in HBM) inside this script.
+  --workload chr20             BASELINE.json configs[1]: 64,444,167 bp, 1,000 barcodes x 1,000 pairs (round 1's configuration;
+                               its 64 MB index is Infinity-Cache resident, so its seeding roofline is labelled as such).
+
+Reads are resident in HBM when the clock starts; results stay in HBM (PCIe-inclusive numbers: DESIGN.md).
 Inside a step the read set is cut into device batches of whole barcodes, each on its own HIP stream and host thread, so
 that one batch's latency-bound seeding shares the chip with the others' DP kernels.
 
 N > 1 (launched by torch.distributed.run): barcode groups are independent, so every rank aligns its own barcodes on
-its own replica of the index with no data-path collective (weak scaling: each rank gets a full configs[1] read set
-with its own seed); torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+its own replica of the index with no data-path collective (weak scaling: each rank gets a full slice with its own
+seed); torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+
+The same job times the reference's C core on the host cores beside the GPU (cpu_baseline) and checks a sample of the GPU
+results against it bit for bit; a mismatch makes the run fail (parity_ok false, exit code 1).
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,60 +40,80 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INFINITY_CACHE_BYTES = 256 << 20 # MI355X_MICROARCH.md "Infinity Cache": a uniformly read table stays resident up to ~255 MiB
 CHR20_LEN = 64_444_167
-SEED0 = 20250905 + 2             # seed = 20250905 + config#
+GRCH38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+               135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
+               50818468, 156040895, 57227415]      # chr1..22, X, Y of GRCh38: 3,088,269,832 bp (a contig must stay below 2^31, bntann1_t.len)
+WORKLOADS = {
+    # name: contig lengths, barcodes, pairs per barcode, molecules per barcode, seed (20250905 + config#), label
+    # repeat families at scale 1 are SURVEY.md s8d's recipe as written: 10^4 x 300 bp Alu-like at 12 %, 10^3 x 6 kb L1-like at 5 %,
+    # 200 x 50 kb segmental duplications at 1 % (None: make_genome's own scaling, round 1's chr20 genome)
+    "grch38": dict(lens=GRCH38_LENS, barcodes=13000, ppb=77, molecules=4, seed=20250905 + 3,
+                   families=[(10000, 300, 0.12), (1000, 6000, 0.05), (200, 50000, 0.01)],
+                   label="BASELINE.json configs[2] on one GPU: GRCh38-size genome (%d bp synthetic, 24 contigs, planted repeats), TELLseq-like "
+                         "%d barcodes x %d pairs 2x150bp per step per GPU (slice of the 30x set)"),
+    "chr20": dict(lens=[CHR20_LEN - 2_000_000, 1_500_000, 500_000], barcodes=1000, ppb=1000, molecules=10, seed=20250905 + 2, families=None,
+                  label="BASELINE.json configs[1]: GRCh38 chr20-size genome (%d bp synthetic, planted repeats), %d barcodes x %d pairs 2x150bp per GPU"),
+}
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def prepare_index(cache, genome_len, rank, barrier):
-    """Synthetic genome + index (built by the product's own `bwa index` equivalent), cached under /tmp."""
+def prepare_index(cache, name, lens, seed, families, rank, barrier, setup):
+    """Synthetic genome + index (built by the product's own `bwa index` equivalent: suffix sorting in HBM), cached on disk."""
     from arachne_amd import api, synth
-    prefix = os.path.join(cache, f"g{genome_len}.fa")
+    total = int(sum(lens))
+    prefix = os.path.join(cache, f"{name}_{total}.fa")
     done = prefix + ".done"
     if rank == 0 and not os.path.exists(done):
         os.makedirs(cache, exist_ok=True)
         t = time.time()
-        # chr20-like: one big contig plus two small ones so that contig clamping is exercised
-        lens = [genome_len - 2_000_000, 1_500_000, 500_000] if genome_len > 8_000_000 else [genome_len]
-        g = synth.make_genome(SEED0, lens)
+        g = synth.make_genome(seed, lens, repeat_families=families, fast=total > 500_000_000)
+        setup["genome_synth_s"] = round(time.time() - t, 2)
+        t = time.time()
         g.write_fasta(prefix)
-        log(f"genome {genome_len} bp written in {time.time() - t:.1f}s")
+        np.save(prefix + ".codes.npy", np.concatenate(g.seqs))
+        np.save(prefix + ".lens.npy", np.array(lens, dtype=np.int64))
+        del g
+        setup["genome_write_s"] = round(time.time() - t, 2)
+        log(f"genome {total} bp synthesised and written in {setup['genome_synth_s'] + setup['genome_write_s']:.1f}s")
         t = time.time()
         api.index_build(prefix, prefix)
-        log(f"index built in {time.time() - t:.1f}s")
-        np.save(prefix + ".lens.npy", np.array(lens, dtype=np.int64))
+        setup["index_build_s"] = round(time.time() - t, 2)
+        log(f"index built in {time.time() - t:.1f}s (arx_index_build: FASTA -> .pac/.ann/.amb on the host, BWT + SA in HBM)")
+        if total > 500_000_000:
+            os.remove(prefix)          # the codes are kept as .npy; the FASTA of a GRCh38-size genome is 3 GB
         open(done, "w").write("ok")
     barrier()
     return prefix
 
 
 def load_genome(prefix):
-    """Re-read the cached FASTA into the synth.Genome shape make_reads() needs."""
+    """The cached genome in the synth.Genome shape make_reads() needs (contigs are views of one memory-mapped array)."""
     from arachne_amd import synth
     lens = np.load(prefix + ".lens.npy")
-    raw = np.fromfile(prefix, dtype=np.uint8)
-    seqs, names, pos = [], [], 0
-    lut = np.full(256, 255, dtype=np.uint8)
-    for i, c in enumerate(b"ACGTN"):
-        lut[c] = i
-    for k, L in enumerate(lens):
-        nl = raw[pos:].tobytes().index(b"\n")
-        names.append(raw[pos + 1:pos + nl].tobytes().decode())
-        pos += nl + 1
-        nlines = (int(L) + 79) // 80
-        body = raw[pos:pos + int(L) + nlines]
-        s = lut[body]
-        seqs.append(s[s != 255])
-        assert len(seqs[-1]) == L, (len(seqs[-1]), L)
-        pos += int(L) + nlines
-    return synth.Genome(names, seqs, [False] * len(seqs))
+    cat = np.load(prefix + ".codes.npy", mmap_mode="r")
+    off = np.concatenate([[0], np.cumsum(lens)])
+    seqs = [cat[int(off[i]):int(off[i + 1])] for i in range(len(lens))]
+    return synth.Genome([f"chrS{i + 1}" for i in range(len(lens))], seqs, [False] * len(seqs))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(prefix, rs, n_sample, cores, l_pac, ann_off):
-    """Reference C core (oracle/_ref, kind "reference") if the prebuilt .so travelled, else our CPU restatement ("port")."""
+    """Reference C core (oracle/_ref, kind "reference") if the prebuilt .so travelled, else our CPU restatement ("port").
+    -> (cpu_baseline dict, the reference's results for the sample, the driver object)"""
     import refdrv
     n = min(n_sample, rs.n_pairs)
     seqs, lens = rs.seqs[:2 * n], rs.lens[:2 * n]
@@ -96,25 +128,38 @@ def cpu_baseline(prefix, rs, n_sample, cores, l_pac, ann_off):
         kind = "port"
     out = r.batch(seqs, lens, n_threads=cores)
     secs = out["secs"]
-    res = dict(value=n / secs, unit="paired reads/s", cores=cores, kind=kind,
+    res = dict(value=n / secs, unit="paired reads/s", cores=cores, kind=kind, cpu_model=cpu_model(), nproc=os.cpu_count(),
                sample=f"first {n} pairs of the same read set, candidate generation + rescue + CIGAR for every candidate "
                       f"(gobwa.go:226-337,400-415 call sequence: the C half of the path), {cores} OpenMP threads, {secs:.1f}s")
-    # the Go half (candidate statistics, RFA placement, MAPQ) has no runnable reference: our single-threaded C
-    # restatement of it on the whole barcodes of the sample is timed as information only, never folded into `value`
-    try:
-        import rfadrv
-        po = rs.pair_offsets()
-        nb = int(np.searchsorted(po, n, side="right")) - 1
-        if nb > 0:
-            npairs = int(po[nb])
-            sub = refdrv_slice(out, 2 * npairs)
-            t = time.time()
-            rfadrv.oracle_rfa(sub, lens[:2 * npairs], po[:nb + 1], [True] * nb, l_pac, ann_off)
-            res["go_half_port_secs"] = time.time() - t
-            res["go_half_port_note"] = f"oracle/arx_oracle_rfa.c on {nb} barcodes ({npairs} pairs), 1 thread"
-    except Exception as e:
-        res["go_half_port_note"] = "not timed: " + repr(e)
-    return res, out
+    # the reference's default is -t 8 (main.go:40): the same code on 8 threads, on a smaller sample
+    n8 = min(n, 24_000)
+    o8 = r.batch(seqs[:2 * n8], lens[:2 * n8], n_threads=8)
+    res["t8"] = dict(value=n8 / o8["secs"], cores=8, sample=f"first {n8} pairs, {o8['secs']:.1f}s")
+    if kind == "reference":   # thread-seconds per phase (seed / extend / rescue / CIGAR), timing-only replay of the same calls
+        ns = min(n, 250 * cores)
+        ph = r.phase_split(seqs[:2 * ns], lens[:2 * ns], n_threads=cores)
+        tot = ph["seed"] + ph["extend"] + ph["rescue"] + ph["cigar"]
+        res["phase_share"] = {k: round(ph[k] / tot, 4) for k in ("seed", "extend", "rescue", "cigar")}
+        res["phase_note"] = (f"thread-seconds on {ns} pairs, {cores} threads: seed = mem_chain .. mem_flt_chained_seeds (SMEM, locate, chaining), extend = "
+                             "mem_chain2aln + mem_sort_dedup_patch, rescue = mem_matesw loops, cigar = mem_reg2aln")
+    return res, out, r
+
+
+def go_half_port(rs, ref_out, n, l_pac, ann_off):
+    """The Go half (candidate statistics, RFA placement, MAPQ) has no runnable reference: our single-threaded C restatement
+    of it on the whole barcodes inside the first n pairs -> (timing info, its result, pairs covered, barcode offsets)."""
+    import rfadrv
+    po = rs.pair_offsets()
+    nb = int(np.searchsorted(po, n, side="right")) - 1
+    if nb <= 0:
+        return None
+    npairs = int(po[nb])
+    sub = refdrv_slice(ref_out, 2 * npairs)
+    flags = [True] * nb
+    t = time.time()
+    orfa = rfadrv.oracle_rfa(sub, rs.lens[:2 * npairs], po[:nb + 1], flags, l_pac, ann_off)
+    secs = time.time() - t
+    return dict(secs=secs, note=f"oracle/arx_oracle_rfa.c on {nb} barcodes ({npairs} pairs), 1 thread"), orfa, npairs, po[:nb + 1], flags
 
 
 def algorithmic_bytes(prefix, rs, n_sample):
@@ -135,8 +180,11 @@ def algorithmic_bytes(prefix, rs, n_sample):
     per_read_bwd = 64.0 * (c["extb_same_block"] + 2 * c["extb_two_block"]) / reads + L / 4     # backward sweeps (re-read the bases)
     per_read_fwd = 64.0 * ((e1 - c["extb_same_block"]) + 2 * (e2 - c["extb_two_block"])) / reads + L / 4
     per_read_strat = 64.0 * (c["ext3_same_block"] + 2 * c["ext3_two_block"]) / reads + L / 4
-    per_read_locate = (64.0 * c["sa_lf_steps"] + 8.0 * c["sa_lookups"]) / reads
-    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, counters={k: v / reads for k, v in c.items() if k != "n_reads"})
+    per_read_locate = (64.0 * c["sa_lf_steps"] + 8.0 * c["sa_lookups"]) / reads       # the reference's walk: to a sample every 32nd row
+    per_read_locate8 = (64.0 * c["sa_lf_steps8"] + 8.0 * c["sa_lookups"]) / reads     # the same lookups walked to a sample every 8th row
+    o.close()
+    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, locate8=per_read_locate8,
+                counters={k: v / reads for k, v in c.items() if k != "n_reads"})
 
 
 def main():
@@ -144,9 +192,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--barcodes", type=int, default=1000)
-    ap.add_argument("--pairs-per-barcode", type=int, default=1000)
-    ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
+    ap.add_argument("--workload", default="grch38", choices=sorted(WORKLOADS), help="grch38: the configuration the metric is quoted on (default); chr20: configs[1]")
+    ap.add_argument("--barcodes", type=int, default=0, help="override the workload's barcodes per step")
+    ap.add_argument("--pairs-per-barcode", type=int, default=0, help="override the workload's pairs per barcode")
+    ap.add_argument("--genome-len", type=int, default=0, help="(experiments) one big contig of this length plus two small ones instead of the workload's genome")
     ap.add_argument("--chunk-pairs", type=int, default=350_000, help="pairs per device batch inside one step")
     ap.add_argument("--streams", type=int, default=3, help="device batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
@@ -186,18 +235,31 @@ def main():
             pass
 
     from arachne_amd import api, synth
-    prefix = prepare_index(args.cache, args.genome_len, rank, barrier)
-    genome = load_genome(prefix)
-    t = time.time()
-    rs = synth.make_reads(SEED0 + 1000 * rank, genome, args.barcodes, args.pairs_per_barcode)
-    log(f"rank {rank}: {rs.n_pairs} pairs synthesised in {time.time() - t:.1f}s")
-
+    wl = dict(WORKLOADS[args.workload])
+    if args.genome_len:
+        wl["lens"] = [args.genome_len - 2_000_000, 1_500_000, 500_000] if args.genome_len > 8_000_000 else [args.genome_len]
+    n_barcodes, ppb = args.barcodes or wl["barcodes"], args.pairs_per_barcode or wl["ppb"]
+    genome_len = int(sum(wl["lens"]))
+    SEED0 = wl["seed"]
+    setup = {}
     if args.lib:
         api.LIB_PATH = args.lib
+    prefix = prepare_index(args.cache, args.workload if not args.genome_len else "custom", wl["lens"], SEED0, wl["families"], rank, barrier, setup)
+    genome = load_genome(prefix)
+    t = time.time()
+    rs = synth.make_reads(SEED0 + 1000 * (rank + 1), genome, n_barcodes, ppb, molecules_per_barcode=wl["molecules"], fast=n_barcodes * ppb > 1_500_000)
+    setup["reads_synth_s"] = round(time.time() - t, 2)
+    log(f"rank {rank}: {rs.n_pairs} pairs synthesised in {time.time() - t:.1f}s")
+    del genome
+
+    t = time.time()
+    if args.lib:
         ref = api.Reference(prefix, local_rank, lib_path=args.lib)
     else:
         ref = api.load_reference(prefix, device=local_rank)
         assert ref.backend == "hip:gfx950", ref.backend
+    setup["arx_open_s"] = round(time.time() - t, 2)
+    index_bytes = {ext: os.path.getsize(prefix + "." + ext) for ext in ("bwt", "sa", "pac")}
     # whole barcodes per device batch; reads go to HBM before the clock starts
     po = rs.pair_offsets()
     # `depth` handles per chunk of the read set: step s works on set s % depth, so that the first batches of a step can start while
@@ -295,25 +357,33 @@ def main():
     ktimes_iso = ref.kernel_times()
     ref.kernel_times_reset(False)
     # what every rank did (control plane only; the data path has no collective): pairs and regions per step
-    mine = dict(rank=rank, pairs=int(rs.n_pairs), regs=int(sum(c["n_regs"] for c in counts)), read_seed=SEED0 + 1000 * rank)
+    mine = dict(rank=rank, pairs=int(rs.n_pairs), regs=int(sum(c["n_regs"] for c in counts)), read_seed=SEED0 + 1000 * (rank + 1))
     per_rank = [mine]
     if dist is not None:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
+    parity_failed = None
     if rank == 0:
         pairs_per_step = sum(r["pairs"] for r in per_rank)
         value = pairs_per_step * args.steps / dt
         baseline = json.load(open(os.path.join(ROOT, "BASELINE.json"))) if os.path.exists(os.path.join(ROOT, "BASELINE.json")) else {}
         out = dict(metric=baseline.get("metric", "paired reads/sec at 1/2/4/8 MI355X, GRCh38 2x150bp; CIGAR/MAPQ match vs CPU"),
-                   metric_detail="read pairs per second through the whole per-barcode path (seed + extend + rescue + CIGAR%s), results left in HBM" % ("" if args.no_rfa else " + RFA placement + MAPQ" + (" + CIGAR walk/markDuplicates/split reads" if args.post else "")),
+                   metric_detail="read pairs per second through the whole per-barcode path (seed + extend + rescue + CIGAR%s), reads resident in HBM before the clock starts, results left in HBM (transfers excluded)" % ("" if args.no_rfa else " + RFA placement + MAPQ" + (" + CIGAR walk/markDuplicates/split reads" if args.post else "")),
                    value=value, unit="paired reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1000.0 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u8/i16/i32 integer (max-plus DP) + u64 (FM-index)", data="synthetic",
-                   config=dict(workload="BASELINE.json configs[1]: GRCh38 chr20-size genome (%d bp synthetic, planted repeats), "
-                                        "%d barcodes x %d pairs 2x150bp per GPU" % (args.genome_len, args.barcodes, args.pairs_per_barcode),
-                               pairs_per_step_per_gpu=rs.n_pairs, device_batches=len(batches), parallelism=f"barcode-sharded x{world}"))
+                   config=dict(workload=wl["label"] % (genome_len, n_barcodes, ppb), genome_bp=genome_len,
+                               index_bytes_in_files=index_bytes, pairs_per_step_per_gpu=rs.n_pairs, device_batches=len(batches),
+                               parallelism=f"barcode-sharded x{world}"))
         out["per_rank"] = per_rank
+        out["setup_s"] = setup
+        # where the FM-index lives decides what the seeding kernels are bound by: a table under 256 MiB stays in the Infinity Cache
+        occ_bytes = index_bytes["bwt"]
+        in_hbm = occ_bytes > INFINITY_CACHE_BYTES
+        bound = "hbm" if in_hbm else "infinity-cache"
+        bound_note = ("Occ/BWT table %.2f GB in HBM, scattered 64-byte block reads" % (occ_bytes / 1e9)) if in_hbm else \
+            ("Occ/BWT table %.0f MB fits the 256 MiB Infinity Cache: the fraction below is against the HBM peak for comparison only, it is not an HBM measurement" % (occ_bytes / 1e6))
         # roofline of the seeding kernel (the HBM-bound headline)
         try:
             ab = algorithmic_bytes(prefix, rs, 10_000)
@@ -334,13 +404,14 @@ def main():
                 # memory-side bytes of the same kernels from the committed rocprofv3 --pmc FETCH_SIZE pass of this command (counters
                 # cannot be read from inside the process); null when no such pass is committed
                 traffic, traffic_src = None, None
-                tf = os.path.join(ROOT, "profiles", "r01", "seed_traffic.json")
+                rel = os.path.join("profiles", "r02", "seed_traffic_%s.json" % args.workload)
+                tf = os.path.join(ROOT, rel)
                 if os.path.exists(tf):
                     tj = json.load(open(tf))
                     if "bwd_fabric_bytes_per_read" in tj:
                         traffic = tj["bwd_fabric_bytes_per_read"] * reads_per_launch / launches_per_batch
-                        traffic_src = "profiles/r01/seed_traffic.json"
-                out["roofline"] = dict(kernel="seed_bwd (k_seed_bwd + k_seed_bwd_wave: backward sweeps of bwt_smem1a, bwt_extend/bwt_2occ4)", bound="hbm",
+                        traffic_src = rel
+                out["roofline"] = dict(kernel="seed_bwd (k_seed_bwd + k_seed_bwd_wave: backward sweeps of bwt_smem1a, bwt_extend/bwt_2occ4)", bound=bound, bound_note=bound_note,
                                        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                                        traffic_unit="bytes per launch", traffic_source=traffic_src, algorithmic_bytes_per_read=ab["bwd"],
                                        reads_per_launch=reads_per_launch, launches_per_batch=launches_per_batch, avg_launch_ms=avg_ms)
@@ -358,28 +429,31 @@ def main():
                 if runs:
                     tot = (ab["seed"] + ab["strat"]) * reads_per_launch
                     ach = tot / (sms / runs * 1e-3) / 1e9
-                    out[key] = dict(kernels=stage, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    out[key] = dict(kernels=stage, bound=bound, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                                     algorithmic_bytes_per_read=ab["seed"] + ab["strat"], ms_per_batch=sms / runs)
             ms, calls = group(ktimes, ["seed_fwd"])
             if calls:
                 avg_ms = ms / calls
                 ach = ab["fwd"] * reads_per_launch / 2.0 / (avg_ms * 1e-3) / 1e9
-                out["roofline_fwd"] = dict(kernel="seed_fwd (k_seed_fwd1 / k_seed_fwd2: forward extensions of bwt_smem1a)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                out["roofline_fwd"] = dict(kernel="seed_fwd (k_seed_fwd1 / k_seed_fwd2: forward extensions of bwt_smem1a)", bound=bound, achieved=ach, peak=HBM_PEAK_GBS,
                                            unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["fwd"], avg_launch_ms=avg_ms)
             ks3 = ktimes.get("seed_strat")
             if ks3 and ks3["calls"]:
                 avg_ms = ks3["ms"] / ks3["calls"]
                 ach = ab["strat"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
-                out["roofline_strat"] = dict(kernel="seed_strat (k_strat_dyn: bwt_seed_strategy1, third seeding pass)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                out["roofline_strat"] = dict(kernel="seed_strat (k_strat_dyn: bwt_seed_strategy1, third seeding pass)", bound=bound, achieved=ach, peak=HBM_PEAK_GBS,
                                              unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["strat"], avg_launch_ms=avg_ms)
             kl = ktimes.get("locate")
             if kl and kl["calls"]:
                 avg_ms = kl["ms"] / kl["calls"]
-                ach = ab["locate"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
-                out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                                              frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms,
-                                              note="algorithmic bytes are those of the reference's walk to a sample every 32nd row; the device walks to the sample "
-                                                   "every %s-th row it builds at arx_open and moves about a quarter of them" % os.environ.get("ARX_SA_DENSE", "8"))
+                # the bytes of the walk the kernel does: the same lookups, each walked to the first row that is a multiple of the
+                # device's sample interval (counted by the restatement for 8; the reference's own walk to every 32nd row beside it)
+                dense = int(os.environ.get("ARX_SA_DENSE", "8"))
+                per_read = ab["locate8"] if dense == 8 else ab["locate"]
+                ach = per_read * reads_per_launch / (avg_ms * 1e-3) / 1e9
+                out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk to the suffix-array sample every %d-th row)" % dense, bound=bound,
+                                              achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=per_read,
+                                              reference_walk_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms)
             out["work_per_read"] = ab["counters"]
         except Exception as e:  # the roofline needs the oracle library; never fail the throughput line over it
             log("roofline skipped:", repr(e))
@@ -390,21 +464,40 @@ def main():
                              ext_dp_per_pair=sum(c["n_ext"] for c in counts) / rs.n_pairs, sw_per_pair=sum(c["n_sw"] for c in counts) / rs.n_pairs,
                              regs_per_read=sum(c["n_regs"] for c in counts) / (2.0 * rs.n_pairs))
         if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            n_sample = args.cpu_sample or min(rs.n_pairs, 2000 * cores)
+            _n, offs, _l, _a, l_pac = ref.contigs()
+            cb = ref_out = None
             try:
-                cores = os.cpu_count() or 1
-                n_sample = args.cpu_sample or min(rs.n_pairs, 4000 * cores)
-                _n, offs, _l, _a, l_pac = ref.contigs()
-                cb, ref_out = cpu_baseline(prefix, rs, n_sample, cores, l_pac, offs)
+                cb, ref_out, _drv = cpu_baseline(prefix, rs, n_sample, cores, l_pac, offs)
                 out["cpu_baseline"] = cb
-                # the same sample through the GPU path must agree with the CPU path it is timed beside
-                import parity
-                n = min(n_sample, 2000)
-                dev = ref.mem_mate_sw(rs.seqs[:2 * n], rs.lens[:2 * n])
-                sub = refdrv_slice(ref_out, 2 * n)
-                parity.check_final(dev, sub)
-                out["parity_checked_pairs"] = n
-            except Exception as e:
+            except (ImportError, OSError, RuntimeError) as e:   # the baseline library is missing or cannot load the index: report, keep the throughput line
                 log("cpu baseline skipped:", repr(e))
+            if ref_out is not None:
+                # The same sample through the GPU path must agree with the CPU path it is timed beside: regions, positions, strands, NM and
+                # CIGARs against the reference's C core, candidates / placement / MAPQ against the restatement of the Go half run on the
+                # reference's C-half output.  A mismatch fails the run.
+                import parity
+                try:
+                    n = min(n_sample, 2000)
+                    gh = go_half_port(rs, ref_out, n, l_pac, offs)
+                    n_chk = gh[2] if gh else n
+                    b = ref.batch(rs.seqs[:2 * n_chk], rs.lens[:2 * n_chk]).run()
+                    dev = b.fetch()
+                    parity.check_final(dev, refdrv_slice(ref_out, 2 * n_chk))
+                    out["parity_checked_pairs"] = n_chk
+                    if gh and not args.no_rfa:
+                        info, orfa, _np, bpo, flags = gh
+                        cb["go_half_port_secs"] = info["secs"]
+                        cb["go_half_port_note"] = info["note"]
+                        parity.check_rfa(b.rfa(bpo, flags), orfa)
+                        out["parity_checked_rfa_barcodes"] = len(flags)
+                    b.free()
+                    out["parity_ok"] = True
+                except AssertionError as e:
+                    out["parity_ok"] = False
+                    out["parity_error"] = str(e)[:500]
+                    parity_failed = str(e)
         print(json.dumps(out), flush=True)
     for bs in sets:
         for b in bs:
@@ -413,6 +506,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_failed:
+        log("PARITY MISMATCH between the GPU path and the CPU path:", parity_failed)
+        sys.exit(1)
 
 
 def refdrv_slice(out, n_reads):

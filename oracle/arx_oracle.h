@@ -37,6 +37,7 @@ typedef struct {
 	int64_t ext3_same_block, ext3_two_block; /* the share of E1 / E2 spent in the third seeding pass (bwt_seed_strategy1) */
 	int64_t extb_same_block, extb_two_block; /* the share spent in backward extensions (the backward sweeps of bwt_smem1a) */
 	int64_t n_smem_calls;                    /* bwt_smem1a calls (first pass + re-seeding) */
+	int64_t sa_lf_steps8;                    /* LF steps of the same lookups up to the first row that is a multiple of 8 */
 } ora_counters_t;
 
 #ifdef __cplusplus

@@ -334,6 +334,88 @@ double ref_batch_run(ref_ctx_t *c, int64_t n_pairs, const uint8_t *seqs, const i
 	return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+/* ---- per-phase split of the CPU time (seed / extend / rescue / CIGAR), for bench.py's cpu_baseline only.  The same
+ * reference functions in the same order as do_pair(); mem_align1_core (bwamem.c:1048-1084) is replayed call by call so that the
+ * clock can be read between seeding (mem_chain .. mem_flt_chained_seeds) and extension (mem_chain2aln .. mem_sort_dedup_patch).
+ * Results are thrown away; out[4] = thread-seconds summed over the threads, out[4] = regions found (cross-check). */
+static inline double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+static mem_alnreg_v timed_align1(const ref_ctx_t *c, int l_seq, char *seq, double *t_seed, double *t_ext)
+{
+	const mem_opt_t *opt = c->opt;
+	const bwaidx_t *idx = c->idx;
+	mem_chain_v chn;
+	mem_alnreg_v regs;
+	int i;
+	double t0 = now_s(), t1;
+	chn = mem_chain(opt, idx->bwt, idx->bns, l_seq, (uint8_t*)seq, 0);
+	chn.n = mem_chain_flt(opt, chn.n, chn.a);
+	mem_flt_chained_seeds(opt, idx->bns, idx->pac, l_seq, (uint8_t*)seq, chn.n, chn.a);
+	t1 = now_s(); *t_seed += t1 - t0;
+	kv_init(regs);
+	for (i = 0; i < (int)chn.n; ++i) {
+		mem_chain2aln(opt, idx->bns, idx->pac, l_seq, (uint8_t*)seq, &chn.a[i], &regs);
+		free(chn.a[i].seeds);
+	}
+	free(chn.a);
+	regs.n = mem_sort_dedup_patch(opt, idx->bns, idx->pac, (uint8_t*)seq, regs.n, regs.a);
+	for (i = 0; i < (int)regs.n; ++i)
+		if (regs.a[i].rid >= 0 && idx->bns->anns[regs.a[i].rid].is_alt) regs.a[i].is_alt = 1;
+	*t_ext += now_s() - t1;
+	return regs;
+}
+
+double ref_phase_split(ref_ctx_t *c, int64_t n_pairs, const uint8_t *seqs, const int32_t *lens, int score_delta, int n_threads, double *out)
+{
+	int64_t *off = (int64_t*)malloc((2 * n_pairs + 1) * 8), i;
+	double T[4] = {0, 0, 0, 0}, n_regs = 0, w0, w1;
+	off[0] = 0;
+	for (i = 0; i < 2 * n_pairs; ++i) off[i + 1] = off[i] + lens[i];
+	w0 = now_s();
+#ifdef _OPENMP
+	if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 16) reduction(+:T[:4], n_regs)
+#endif
+	for (i = 0; i < n_pairs; ++i) {
+		const int l1 = lens[2*i], l2 = lens[2*i+1];
+		mem_pestat_t pes[4];
+		mem_alnreg_v r[2];
+		char *q[2];
+		int k, e, num, best[2] = {0, 0}, n_snap;
+		mem_alnreg_t *snap;
+		double t0;
+		fixed_pes(pes);
+		q[0] = (char*)malloc(l1 + 1); q[1] = (char*)malloc(l2 + 1);
+		memcpy(q[0], seqs + off[2*i], l1); memcpy(q[1], seqs + off[2*i+1], l2);
+		memset(r, 0, sizeof r);
+		if (l1 > 0) r[0] = timed_align1(c, l1, q[0], &T[0], &T[1]);
+		if (l2 > 0) r[1] = timed_align1(c, l2, q[1], &T[0], &T[1]);
+		for (e = 0; e < 2; ++e) for (k = 0; k < (int)r[e].n; ++k) if (r[e].a[k].score > best[e]) best[e] = r[e].a[k].score;
+		t0 = now_s();
+		n_snap = r[1].n; snap = r[1].a;
+		for (k = 0, num = 0; k < n_snap && num < 50 && l1 > 0; ++k)
+			if (snap[k].score >= best[1] - score_delta) { ++num; mem_matesw(c->opt, c->idx->bns, c->idx->pac, pes, &snap[k], l1, (uint8_t*)q[0], &r[0]); }
+		n_snap = r[0].n; snap = r[0].a;
+		for (k = 0, num = 0; k < n_snap && num < 50 && l2 > 0; ++k)
+			if (snap[k].score >= best[0] - score_delta) { ++num; mem_matesw(c->opt, c->idx->bns, c->idx->pac, pes, &snap[k], l2, (uint8_t*)q[1], &r[1]); }
+		T[2] += now_s() - t0;
+		t0 = now_s();
+		for (e = 0; e < 2; ++e)
+			for (k = 0; k < (int)r[e].n; ++k) {
+				mem_aln_t a = mem_reg2aln(c->opt, c->idx->bns, c->idx->pac, e ? l2 : l1, q[e], &r[e].a[k]);
+				free(a.cigar);
+			}
+		T[3] += now_s() - t0;
+		n_regs += r[0].n + r[1].n;
+		free(r[0].a); free(r[1].a); free(q[0]); free(q[1]);
+	}
+	w1 = now_s();
+	for (i = 0; i < 4; ++i) out[i] = T[i];
+	out[4] = n_regs;
+	free(off);
+	return w1 - w0;
+}
+
 void ref_batch_get(ref_ctx_t *c, int64_t *n_reads, int64_t *n_regs, int64_t *n_cig, int64_t **reg_off, int64_t **regs, int64_t **alns, uint32_t **cigars)
 {
 	*n_reads = c->n_reads; *n_regs = c->n_regs; *n_cig = c->n_cig;

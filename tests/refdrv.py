@@ -51,6 +51,8 @@ class Ref:
         L.ref_fetch_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.ref_batch_get.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.ref_n_seqs.argtypes = [C.c_void_p]
+        L.ref_phase_split.restype = C.c_double
+        L.ref_phase_split.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         self.h = None
         if prefix is not None:
             self.open(prefix)
@@ -174,3 +176,12 @@ class Ref:
         alns = np.ctypeslib.as_array(p_alns, shape=(max(nreg, 1), ALN_W))[:nreg].copy()
         cig = np.ctypeslib.as_array(p_cig, shape=(max(nc, 1),))[:nc].copy()
         return dict(reg_off=off, regs=regs, alns=alns, cigars=cig, secs=secs)
+
+    def phase_split(self, seqs2d_or_flat, lens, score_delta=25, n_threads=1):
+        """Thread-seconds of the reference C core per phase on these pairs (timing only; results are discarded):
+        -> dict(seed, extend, rescue, cigar, n_regs, wall)."""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        s = np.ascontiguousarray(seqs2d_or_flat, dtype=np.uint8).reshape(-1)
+        out = np.zeros(5, dtype=np.float64)
+        wall = self.lib.ref_phase_split(self.h, len(lens) // 2, s.ctypes.data, lens.ctypes.data, score_delta, n_threads, out.ctypes.data)
+        return dict(seed=float(out[0]), extend=float(out[1]), rescue=float(out[2]), cigar=float(out[3]), n_regs=int(out[4]), wall=float(wall))
