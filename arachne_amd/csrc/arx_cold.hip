@@ -1,7 +1,7 @@
-// arx_cold.hip -- the two list-bookkeeping kernels (region de-duplication, rescue state machine), compiled at -O1.
-// hipcc 7.2 (AMD clang 22) at -O2/-O3 generates a dedup kernel for gfx950 that never terminates although the same
-// source is correct at -O1, on the host (clang -O3, gcc -O2) and under ASan/UBSan; these kernels are far from any
-// hot spot, so they live in their own translation unit until the miscompile is understood.
+// arx_cold.hip -- the two list-bookkeeping kernels (region de-duplication, rescue state machine) as their own translation unit
+// so that the library's units compile side by side.  Until round 2 this unit was built at -O1: hipcc 7.2 at -O2/-O3 emitted
+// a dedup kernel that never terminated on gfx950.  The cause was bisected to the optimised body of ks_introsort (arx_dev.h has the
+// record and the source form that terminates); the unit is -O3 like the rest.
 #include "hip_rt.h"
 #include "pipeline.h"
 

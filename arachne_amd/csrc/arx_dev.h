@@ -155,13 +155,22 @@ ARX_DEVI int cal_max_gap(int qlen)
 
 // ---- klib introsort on an index array, same comparison sequence as ksort.h:176-226 (unstable; tie order is part of parity).
 // LT is a functor bool(int a, int b) on element indices.
-template <class LT> ARX_DEV void ks_insertsort(int *s, int *t, LT lt)
+#ifndef ARX_SORT_ATTR
+#define ARX_SORT_ATTR // (toolchain experiments: e.g. __attribute__((noinline, optnone)))
+#endif
+#ifndef ARX_SORT_ATTR_INS
+#define ARX_SORT_ATTR_INS ARX_SORT_ATTR
+#endif
+#ifndef ARX_SORT_ATTR_COMB
+#define ARX_SORT_ATTR_COMB ARX_SORT_ATTR
+#endif
+template <class LT> ARX_DEV ARX_SORT_ATTR_INS void ks_insertsort(int *s, int *t, LT lt)
 {
 	for (int *i = s + 1; i < t; ++i)
 		for (int *j = i; j > s && lt(*j, *(j - 1)); --j) { int x = *j; *j = *(j - 1); *(j - 1) = x; }
 }
 
-template <class LT> ARX_DEV void ks_combsort(int n, int *a, LT lt) // ksort.h:154-175
+template <class LT> ARX_DEV ARX_SORT_ATTR_COMB void ks_combsort(int n, int *a, LT lt) // ksort.h:154-175
 {
 	const double shrink = 1.2473309501039786540366528676643;
 	int do_swap, gap = n;
@@ -179,7 +188,61 @@ template <class LT> ARX_DEV void ks_combsort(int n, int *a, LT lt) // ksort.h:15
 	if (gap != 1) ks_insertsort(a, a + n, lt);
 }
 
-template <class LT> ARX_DEV void ks_introsort(int n, int *a, LT lt)
+// The body below is klib's ks_introsort (ksort.h:176-226) with its control flow written in structured form and an iteration budget in
+// its loops -- same comparisons in the same order, so the (unstable) result is klib's.  Why: hipcc 7.2 (AMD clang 22) at -O2/-O3 emits
+// gfx950 code for this function that never terminates inside KDedup / KRescueStep (bisected in round 2: everything else of those
+// kernels at -O3 with only this function `optnone` passes every GPU test; `noinline` alone still hangs; the structured form alone still
+// hangs; with one more exit edge in the loops -- the budget below, which cannot run out: the loops make fewer than 4 (n + 8)^2 steps
+// in total -- the same -O3 build terminates and is bit-identical; stand-alone kernels around the function do not reproduce it,
+// tools/repro_introsort_hang.hip).  DESIGN.md "toolchain notes" has the record.
+#ifndef ARX_INTROSORT_UNSTRUCTURED
+template <class LT> ARX_DEV ARX_SORT_ATTR void ks_introsort(int n, int *a, LT lt)
+{
+	int *st_l[64], *st_r[64], st_d[64], top = 0;
+	int d, rp, x, *s, *t, *i, *j, *k;
+	if (n < 1) return;
+	if (n == 2) { if (lt(a[1], a[0])) { x = a[0]; a[0] = a[1]; a[1] = x; } return; }
+	for (d = 2; (1 << d) < n; ++d) {}
+	s = a; t = a + (n - 1); d <<= 1;
+	bool done = false;
+	long budget = 4L * (n + 8) * (n + 8); // never reached (see above)
+#define ARX_GUARD() if (--budget < 0) return;
+	while (!done) {
+		ARX_GUARD()
+		if (s < t) {
+			--d;
+			if (d == 0) { ks_combsort((int)(t - s) + 1, s, lt); t = s; }
+			else {
+				i = s; j = t; k = i + ((j - i) >> 1) + 1;
+				if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
+				else k = lt(*j, *i) ? i : j;
+				rp = *k;
+				if (k != t) { x = *k; *k = *t; *t = x; }
+				bool more = true;
+				while (more) {
+					++i; while (lt(*i, rp)) { ++i; ARX_GUARD() }
+					--j; while (i <= j && lt(rp, *j)) { --j; ARX_GUARD() }
+					ARX_GUARD()
+					more = j > i;
+					if (more) { x = *i; *i = *j; *j = x; }
+				}
+				x = *i; *i = *t; *t = x;
+				if (i - s > t - i) {
+					if (i - s > 16) { st_l[top] = s; st_r[top] = i - 1; st_d[top] = d; ++top; }
+					s = t - i > 16 ? i + 1 : t;
+				} else {
+					if (t - i > 16) { st_l[top] = i + 1; st_r[top] = t; st_d[top] = d; ++top; }
+					t = i - s > 16 ? i - 1 : s;
+				}
+			}
+		} else if (top == 0) done = true;
+		else { --top; s = st_l[top]; t = st_r[top]; d = st_d[top]; }
+	}
+	ks_insertsort(a, a + n, lt);
+#undef ARX_GUARD
+}
+#else
+template <class LT> ARX_DEV ARX_SORT_ATTR void ks_introsort(int n, int *a, LT lt)
 {
 	int *st_l[64], *st_r[64], st_d[64], top = 0;
 	int d, rp, x, *s, *t, *i, *j, *k;
@@ -215,5 +278,7 @@ template <class LT> ARX_DEV void ks_introsort(int n, int *a, LT lt)
 		}
 	}
 }
+
+#endif
 
 } // namespace arx

@@ -286,7 +286,10 @@ ARX_DEV int patch_reg(const IndexView &ix, const uint8_t *query, const Reg &a, c
 	return score;
 }
 
-ARX_DEV int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, Reg *a, Reg *tmp, int *idx, int32_t *eh, int32_t *patched = nullptr)
+#ifndef ARX_DEDUP_ATTR
+#define ARX_DEDUP_ATTR
+#endif
+ARX_DEV ARX_DEDUP_ATTR int sort_dedup_patch(const IndexView &ix, const uint8_t *query, int n, Reg *a, Reg *tmp, int *idx, int32_t *eh, int32_t *patched = nullptr)
 { // *patched is set when two regions were merged (mem_patch_reg): only then can the result fail to be a fixed point of the pass
 	int m, i, j;
 	if (n <= 1) return n;

@@ -187,8 +187,8 @@ struct HipRT {
 		hipLaunchKernelGGL(k_items<F>, dim3(blocks), dim3(64), 0, stream, f, n);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
-	// "cold" kernels (list bookkeeping: dedup, rescue_step) are instantiated in arx_cold.hip, which is compiled at -O1:
-	// hipcc 7.2 at -O2/-O3 emits a dedup kernel that never terminates on gfx950 ("toolchain notes").
+	// "cold" kernels (list bookkeeping: dedup, rescue_step) are instantiated in arx_cold.hip, a translation unit of its own (-O3 like
+	// the rest since round 2; arx_dev.h ks_introsort has the story of the -O1 build they needed before)
 	template <class F> void launch_cold(const char *nm, int n, const F &f);
 	template <class F> void launch_cold_impl(const char *nm, int n, const F &f, bool wide = false)
 	{

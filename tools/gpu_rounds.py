@@ -12,9 +12,11 @@ import numpy as np
 import bench
 from arachne_amd import api, synth
 n_bc = int(sys.argv[1]) if len(sys.argv) > 1 else 350
-prefix = bench.prepare_index("/tmp/arx_bench_cache", bench.CHR20_LEN, 0, lambda: None)
+wname = sys.argv[2] if len(sys.argv) > 2 else "chr20"
+wl = bench.WORKLOADS[wname]
+prefix = bench.prepare_index("/tmp/arx_bench_cache", wname, wl["lens"], wl["seed"], wl["families"], 0, lambda: None, {})
 g = bench.load_genome(prefix)
-rs = synth.make_reads(bench.SEED0, g, n_bc, 1000)
+rs = synth.make_reads(wl["seed"] + 1000, g, n_bc, wl["ppb"], molecules_per_barcode=wl["molecules"], fast=n_bc * wl["ppb"] > 1_500_000)
 ref = api.load_reference(prefix)
 t_up = time.time()
 b = ref.batch(rs.seqs, rs.lens)
@@ -37,7 +39,7 @@ rows = [r for r in (l.rstrip("\n").split("\t") for l in open(log)) if len(r) == 
 by = collections.defaultdict(list)
 for nm, items, ms in rows:
     by[nm].append((int(items), float(ms)))
-for nm in ("extend", "seed", "ext_step", "sw_u8", "rescue_step", "reg2aln_nw"):
+for nm in ("extend", "ext_step", "sw_u8", "rescue_step", "reg2aln_nw", "chain", "dedup", "mapq", "rfa", "scan", "seed_bwd", "seed_bwd_wave", "seed_fwd"):
     v = by.get(nm, [])
     print(nm, "launches", len(v), "total ms %.2f" % sum(m for _, m in v))
     for i, (it, ms) in enumerate(v[:12]):
