@@ -9,7 +9,10 @@ namespace arx {
 
 // B-tree of minimum degree t = 5: KB_DEFAULT_SIZE 512 with a 40-byte key gives t = ((512-4-8)/(8+40)+1)>>1 (kbtree.h:56,388)
 constexpr int BT_T = 5, BT_MAXK = 2 * BT_T - 1;
-struct BtNode { int32_t is_internal, n; int32_t key[BT_MAXK]; int32_t child[BT_MAXK + 1]; };
+// kpos[j] = Chain::pos of key[j], kept inside the node: a node visit is then one round trip to memory (all key positions of the
+// node at once) instead of a binary search of dependent key -> chain -> pos loads -- what a read in a 200-copy repeat spends its
+// time on (a thread walks the tree once per seed occurrence, several hundred times)
+struct BtNode { int32_t is_internal, n; int32_t key[BT_MAXK]; int32_t child[BT_MAXK + 1]; int64_t kpos[BT_MAXK]; };
 
 struct BTree {
 	BtNode *nodes;      // per-read slice of the node pool
@@ -25,19 +28,25 @@ ARX_DEVI int bt_new(BTree &b)
 	return b.n_nodes++;
 }
 
-// __kb_getp_aux (kbtree.h:117-131): first key >= pos inside one node; *r = sign(pos - key[result])
+// __kb_getp_aux (kbtree.h:117-131): first key >= pos inside one node; *r = sign(pos - key[result]).  The reference finds that
+// key by binary search; the first key >= pos of a sorted node is the same whichever way it is found, here by counting the keys
+// below pos (all loads independent of each other).
 ARX_DEVI int bt_getp_aux(const BTree &b, int xi, int64_t pos, int *r)
 {
 	const BtNode &x = b.nodes[xi];
-	int begin = 0, end = x.n;
-	if (x.n == 0) return -1;
-	while (begin < end) {
-		int mid = (begin + end) >> 1;
-		if (b.ch[x.key[mid]].pos < pos) begin = mid + 1; else end = mid;
-	}
-	if (begin == x.n) { *r = 1; return x.n - 1; }
-	int64_t kp = b.ch[x.key[begin]].pos;
-	*r = (pos > kp) - (pos < kp);
+	const int n = x.n;
+	if (n == 0) return -1;
+	int64_t kp[BT_MAXK];
+#pragma unroll
+	for (int j = 0; j < BT_MAXK; ++j) kp[j] = x.kpos[j];
+	int begin = 0;
+#pragma unroll
+	for (int j = 0; j < BT_MAXK; ++j) begin += (j < n && kp[j] < pos) ? 1 : 0;
+	if (begin == n) { *r = 1; return n - 1; }
+	int64_t kb = kp[0];
+#pragma unroll
+	for (int j = 1; j < BT_MAXK; ++j) if (j == begin) kb = kp[j];
+	*r = (pos > kb) - (pos < kb);
 	if (*r < 0) --begin;
 	return begin;
 }
@@ -63,13 +72,13 @@ ARX_DEVI bool bt_split(BTree &b, int xi, int i, int yi) // __kb_split (kbtree.h:
 	BtNode &x = b.nodes[xi], &y = b.nodes[yi], &z = b.nodes[zi];
 	z.is_internal = y.is_internal;
 	z.n = BT_T - 1;
-	for (int j = 0; j < BT_T - 1; ++j) z.key[j] = y.key[BT_T + j];
+	for (int j = 0; j < BT_T - 1; ++j) { z.key[j] = y.key[BT_T + j]; z.kpos[j] = y.kpos[BT_T + j]; }
 	if (y.is_internal) for (int j = 0; j < BT_T; ++j) z.child[j] = y.child[BT_T + j];
 	y.n = BT_T - 1;
 	for (int j = x.n; j > i; --j) x.child[j + 1] = x.child[j];
 	x.child[i + 1] = zi;
-	for (int j = x.n - 1; j >= i; --j) x.key[j + 1] = x.key[j];
-	x.key[i] = y.key[BT_T - 1];
+	for (int j = x.n - 1; j >= i; --j) { x.key[j + 1] = x.key[j]; x.kpos[j + 1] = x.kpos[j]; }
+	x.key[i] = y.key[BT_T - 1]; x.kpos[i] = y.kpos[BT_T - 1];
 	++x.n;
 	return true;
 }
@@ -90,15 +99,15 @@ ARX_DEV bool bt_put(BTree &b, int ci) // kb_putp + __kb_putp_aux (kbtree.h:193-2
 		BtNode &x = b.nodes[xi];
 		if (!x.is_internal) {
 			int i = bt_getp_aux(b, xi, pos, &r);
-			for (int j = x.n - 1; j > i; --j) x.key[j + 1] = x.key[j];
-			x.key[i + 1] = ci;
+			for (int j = x.n - 1; j > i; --j) { x.key[j + 1] = x.key[j]; x.kpos[j + 1] = x.kpos[j]; }
+			x.key[i + 1] = ci; x.kpos[i + 1] = pos;
 			++x.n;
 			return true;
 		}
 		int i = bt_getp_aux(b, xi, pos, &r) + 1;
 		if (b.nodes[x.child[i]].n == BT_MAXK) {
 			if (!bt_split(b, xi, i, x.child[i])) return false;
-			if (pos > b.ch[x.key[i]].pos) ++i;
+			if (pos > x.kpos[i]) ++i;
 		}
 		xi = x.child[i];
 	}
@@ -138,31 +147,27 @@ ARX_DEVI int test_and_merge(int64_t l_pac, Chain &c, const Seed *occ, int *next,
 	return 0;
 }
 
-ARX_DEV int chain_weight(const Chain &c, const Seed *occ, const int *next) // mem_chain_weight (bwamem.c:213-234)
+ARX_DEV int chain_weight(const Chain &c, const Seed *occ, const int *next) // mem_chain_weight (bwamem.c:213-234): both coverages in one walk of the list
 {
-	int64_t end = 0;
-	int w = 0, tmp;
+	int64_t qend = 0, rend = 0;
+	int wq = 0, wr = 0;
 	for (int g = c.head; g >= 0; g = next[g]) {
 		const Seed s = occ[g];
-		if (s.qbeg >= end) w += s.len;
-		else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
-		end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+		if (s.qbeg >= qend) wq += s.len;
+		else if (s.qbeg + s.len > qend) wq += (int)(s.qbeg + s.len - qend);
+		qend = qend > s.qbeg + s.len ? qend : s.qbeg + s.len;
+		if (s.rbeg >= rend) wr += s.len;
+		else if (s.rbeg + s.len > rend) wr += (int)(s.rbeg + s.len - rend);
+		rend = rend > s.rbeg + s.len ? rend : s.rbeg + s.len;
 	}
-	tmp = w; w = 0; end = 0;
-	for (int g = c.head; g >= 0; g = next[g]) {
-		const Seed s = occ[g];
-		if (s.rbeg >= end) w += s.len;
-		else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
-		end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
-	}
-	w = w < tmp ? w : tmp;
+	const int w = wr < wq ? wr : wq;
 	return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
 struct WeightGt { const Chain *c; ARX_DEVI bool operator()(int a, int b) const { return c[a].w > c[b].w; } };
 
 // One read: occurrences [g0, g1) (already located, in interval order) -> filtered chains + their seeds, compacted.
-// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 2*(g1-g0) ints, nodes cap_nodes entries.
+// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 4*(g1-g0) ints, nodes cap_nodes entries.
 // Returns the number of chains kept (mem_chain + mem_chain_flt), or -1 on pool exhaustion.
 ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int n_intv, const Seed *occ, int n_occ,
                              int *next, Chain *ctmp, BtNode *nodes, int cap_nodes, int *iscr, Chain *cout, Seed *sout, int sout_base)
@@ -201,7 +206,7 @@ ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int 
 		}
 	}
 	if (n_ch == 0) return 0;
-	int *ord = iscr, *kept_idx = iscr + n_occ;
+	int *ord = iscr, *kept_idx = iscr + n_occ, *qb_ = iscr + 2 * n_occ, *qe_ = iscr + 3 * n_occ; // iscr: 4 * n_occ ints
 	int n = bt_traverse(bt, ord); // chains in key order = the array mem_chain returns
 	// mem_chain_flt (bwamem.c:327-385)
 	for (int i = 0; i < n; ++i) { Chain &c = ctmp[ord[i]]; c.first = -1; c.kept = 0; c.w = chain_weight(c, occ, next); }
@@ -210,29 +215,30 @@ ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int 
 	int n_kept = 0;
 	ctmp[ord[0]].kept = 3;
 	kept_idx[n_kept++] = 0;
-#define CHN_BEG(c) (occ[(c).head].qbeg)
-#define CHN_END(c) (occ[(c).tail].qbeg + occ[(c).tail].len)
+	for (int i = 0; i < n; ++i) { const Chain &c = ctmp[ord[i]]; qb_[i] = occ[c.head].qbeg; qe_[i] = occ[c.tail].qbeg + occ[c.tail].len; } // chn_beg / chn_end (bwamem.c:325-326)
 	for (int i = 1; i < n; ++i) {
 		Chain &ci = ctmp[ord[i]];
+		const int bi = qb_[i], ei = qe_[i], wi = ci.w, alt_i = ci.is_alt;
 		int large_ovlp = 0, k;
 		for (k = 0; k < n_kept; ++k) {
-			Chain &cj = ctmp[ord[kept_idx[k]]];
-			int b_max = CHN_BEG(cj) > CHN_BEG(ci) ? CHN_BEG(cj) : CHN_BEG(ci);
-			int e_min = CHN_END(cj) < CHN_END(ci) ? CHN_END(cj) : CHN_END(ci);
-			if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
-				int li = CHN_END(ci) - CHN_BEG(ci), lj = CHN_END(cj) - CHN_BEG(cj);
-				int min_l = li < lj ? li : lj;
-				if ((float)(e_min - b_max) >= min_l * OPT_MASK_LEVEL && min_l < OPT_MAX_CHAIN_GAP) {
-					large_ovlp = 1;
-					if (cj.first < 0) cj.first = i;
-					if ((float)ci.w < cj.w * OPT_DROP_RATIO && cj.w - ci.w >= OPT_MIN_SEED_LEN << 1) break;
+			const int kj = kept_idx[k];
+			const int bj = qb_[kj], ej = qe_[kj];
+			const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+			if (e_min > b_max) {
+				Chain &cj = ctmp[ord[kj]];
+				if (!cj.is_alt || alt_i) {
+					const int li = ei - bi, lj = ej - bj;
+					const int min_l = li < lj ? li : lj;
+					if ((float)(e_min - b_max) >= min_l * OPT_MASK_LEVEL && min_l < OPT_MAX_CHAIN_GAP) {
+						large_ovlp = 1;
+						if (cj.first < 0) cj.first = i;
+						if ((float)wi < cj.w * OPT_DROP_RATIO && cj.w - wi >= OPT_MIN_SEED_LEN << 1) break;
+					}
 				}
 			}
 		}
 		if (k == n_kept) { kept_idx[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
 	}
-#undef CHN_BEG
-#undef CHN_END
 	for (int i = 0; i < n_kept; ++i) {
 		const Chain &c = ctmp[ord[kept_idx[i]]];
 		if (c.first >= 0) ctmp[ord[c.first]].kept = 1;

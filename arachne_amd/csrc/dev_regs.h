@@ -355,6 +355,7 @@ struct ResState {
 	uint64_t spec_mask;    // bit k: the k-th anchor above the score threshold had its SW queued ahead
 	int32_t clean[2];      // clean[o]: read o's list is a fixed point of mem_sort_dedup_patch (see matesw_apply)
 	int32_t e, i, num, n_snap, best[2], phase, spec_off; // phase 0: replaying, 1: waiting for a single SW, 2: finished, 3: loop `e` not enumerated yet
+	int32_t mask_fresh, pad; // 1: the mate list is still the one spec_mask was computed against (nothing applied since): the replay trusts the mask
 };
 struct SwTask { int64_t rb, re; int32_t pair, o, slot, pad; };
 struct SwEmit { SwTask *tasks; int32_t *n_tasks, *n_slots; int32_t single_slot, no_ahead; }; // no_ahead (tests): queue nothing ahead, every SW takes the single path; n_tasks: this round's queue; n_slots: result slots handed out so far (they live until the stage ends); single_slot: this pair's phase-1 result
@@ -457,12 +458,13 @@ ARX_DEV int dedup_insert(const Reg &b_in, Reg *ma, int n, Reg *tmp, int *idx)
 // each other and found distinct (the overlap test does not depend on which of two equal-`re` regions comes first), the final
 // order is the strict order by (score, rb, qb), and n_comp is 1 throughout.  So once the list has been through it (*clean)
 // and until something is inserted again the call is skipped, and an insertion into such a list takes dedup_insert().
-ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Res &aln, int64_t rb, Reg *ma, int n_ma, Reg *tmp, int *idx, int32_t *clean)
+ARX_DEV int matesw_apply(const IndexView &ix, const Reg &a, int l_ms, const U8Res &aln, int64_t rb, Reg *ma, int n_ma, Reg *tmp, int *idx, int32_t *clean, int32_t *fresh)
 {
 	const int64_t l_pac = ix.l_pac;
 	const bool inserts = aln.score >= OPT_MIN_SEED_LEN && aln.qb >= 0;
 	ARX_STAT_RESCUE(pair_id_for_stats, n_ma, inserts, *clean);
 	if (!inserts && *clean) return n_ma;
+	*fresh = 0; // the list may change from here on
 	if (inserts) { // is_rev == 1 for the FR orientation
 		Reg b = Reg();
 		b.rb = b.re = 0; b.truesc = b.sub = b.alt_sc = b.sub_n = b.w = b.secondary_all = b.seedlen0 = b.n_comp = 0; b.frac_rep = 0.f; b.pad = 0;
@@ -506,30 +508,43 @@ ARX_DEVI bool rescue_window(const IndexView &ix, const Reg &a, int l_ms, int64_t
 }
 ARX_DEVI bool rescue_skipped(const IndexView &ix, const Reg &a, const Reg *ma, int n_ma) // bwamem_pair.c:118-124
 {
-	for (int j = 0; j < n_ma; ++j) {
-		int64_t dist;
-		int r = infer_dir(ix.l_pac, a.rb, ma[j].rb, &dist);
-		if (r == 1 && dist >= PES_LOW && dist <= PES_HIGH) return true;
+	// eight list entries per round trip to memory: the loads of a group do not depend on each other (a pair in a 200-copy repeat
+	// walks 50 anchors over a 200-entry mate list, one thread)
+	for (int j0 = 0; j0 < n_ma; j0 += 8) {
+		int64_t rb[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) rb[u] = ma[j0 + u < n_ma ? j0 + u : n_ma - 1].rb;
+		bool hit = false;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			int64_t dist;
+			const int r = infer_dir(ix.l_pac, a.rb, rb[u], &dist);
+			hit = hit || (r == 1 && dist >= PES_LOW && dist <= PES_HIGH); // entries past the end repeat the last one: same answer
+		}
+		if (hit) return true;
 	}
 	return false;
 }
 
-// Every SW loop st.e would run against the mate list as it is now.  out == nullptr: count only.
+// Every SW loop st.e would run against the mate list as it is now.  out == nullptr: count only and compute *mask; otherwise *mask is
+// the result of the counting pass (nothing changed in between) and says which anchors get a task.
 ARX_DEV int rescue_enumerate(const IndexView &ix, int pair, const int *lens2, Reg *const regs[2], int *const n_regs[2], const ResState &st, uint64_t *mask,
                              SwTask *out, int slot0)
 {
 	const int e = st.e, o = 1 - e, l_ms = lens2[o];
 	int num = 0, cnt = 0;
-	*mask = 0;
+	const uint64_t known = *mask;
+	if (!out) *mask = 0;
 	if (l_ms <= 0) return 0;
 	for (int i = 0; i < st.n_snap && num < MAX_RESCUE; ++i) {
 		const Reg a = regs[e][i];
 		if (a.score < st.best[e] - 25) continue;
 		const int k = num++;
-		if (rescue_skipped(ix, a, regs[o], *n_regs[o])) continue;
+		if (out) { if (!(known >> k & 1)) continue; }
+		else if (rescue_skipped(ix, a, regs[o], *n_regs[o])) continue;
 		int64_t rb, re;
 		if (!rescue_window(ix, a, l_ms, &rb, &re)) continue;
-		*mask |= (uint64_t)1 << k;
+		if (!out) *mask |= (uint64_t)1 << k;
 		if (out) { SwTask t; t.rb = rb; t.re = re; t.pair = pair; t.o = o; t.slot = slot0 + cnt; t.pad = 0; out[cnt] = t; }
 		++cnt;
 	}
@@ -548,6 +563,7 @@ ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *c
 			int cnt = emit.no_ahead ? 0 : rescue_enumerate(ix, pair, lens2, regs, n_regs, st, &mask, nullptr, 0);
 			if (emit.no_ahead) mask = 0;
 			st.spec_mask = mask; st.spec_off = 0; st.i = 0; st.num = 0; st.phase = 0;
+			st.mask_fresh = emit.no_ahead ? 0 : 1;
 			if (cnt > 0) {
 				st.spec_off = ARX_ATOMIC_ADD(emit.n_slots, cnt);
 				rescue_enumerate(ix, pair, lens2, regs, n_regs, st, &mask, emit.tasks + ARX_ATOMIC_ADD(emit.n_tasks, cnt), st.spec_off);
@@ -556,7 +572,7 @@ ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *c
 		}
 		const int e = st.e, o = 1 - e;
 		if (st.phase == 1) { // the single SW came back: ma = the other read's list
-			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], sres[emit.single_slot], st.rb, regs[o], *n_regs[o], tmp[o], idx[o], &st.clean[o]);
+			*n_regs[o] = matesw_apply(ix, regs[e][st.i], lens2[o], sres[emit.single_slot], st.rb, regs[o], *n_regs[o], tmp[o], idx[o], &st.clean[o], &st.mask_fresh);
 			st.phase = 0; ++st.i;
 		}
 		if (st.i >= st.n_snap || st.num >= MAX_RESCUE || lens2[o] <= 0) {
@@ -567,12 +583,14 @@ ARX_DEV bool rescue_step(const IndexView &ix, int pair, const int *lens2, Reg *c
 		const Reg a = regs[e][st.i];
 		if (a.score < st.best[e] - 25) { ++st.i; continue; } // threshold stays the PRE-rescue best (gobwa.go:302-312)
 		const int k = st.num++;
-		if (rescue_skipped(ix, a, regs[o], *n_regs[o])) { ++st.i; continue; }
+		// while the mate list is the one the mask was computed against, the mask is the answer of both tests below
+		if (st.mask_fresh && !(st.spec_mask >> k & 1)) { ++st.i; continue; }
+		if (!st.mask_fresh && rescue_skipped(ix, a, regs[o], *n_regs[o])) { ++st.i; continue; }
 		int64_t rb, re;
 		if (!rescue_window(ix, a, lens2[o], &rb, &re)) { ++st.i; continue; } // nothing aligned: ma stays as it is
 		if (st.spec_mask >> k & 1) {
 			const int slot = st.spec_off + __builtin_popcountll(st.spec_mask & (((uint64_t)1 << k) - 1));
-			*n_regs[o] = matesw_apply(ix, a, lens2[o], sres[slot], rb, regs[o], *n_regs[o], tmp[o], idx[o], &st.clean[o]);
+			*n_regs[o] = matesw_apply(ix, a, lens2[o], sres[slot], rb, regs[o], *n_regs[o], tmp[o], idx[o], &st.clean[o], &st.mask_fresh);
 			++st.i;
 			continue;
 		}
