@@ -82,9 +82,9 @@ def test_segdup_reads_hostsim(built):
 
 @pytest.mark.gpu
 def test_segdup_reads_gpu(built):
-    g, rs = _segdup_workload(72, 3_000_000, 120, 8, 250)
+    g, rs = _segdup_workload(72, 6_000_000, 200, 8, 250)
     dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, stages=True)
-    assert np.diff(ob["reg_off"]).max() >= 50
+    assert np.diff(ob["reg_off"]).max() >= 40
 
 
 def _one_barcode(seed, genome_len, n_pairs):
