@@ -167,7 +167,7 @@ ARX_DEV int chain_weight(const Chain &c, const Seed *occ, const int *next) // me
 struct WeightGt { const Chain *c; ARX_DEVI bool operator()(int a, int b) const { return c[a].w > c[b].w; } };
 
 // One read: occurrences [g0, g1) (already located, in interval order) -> filtered chains + their seeds, compacted.
-// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 4*(g1-g0) ints, nodes cap_nodes entries.
+// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 7*(g1-g0) ints, nodes cap_nodes entries.
 // Returns the number of chains kept (mem_chain + mem_chain_flt), or -1 on pool exhaustion.
 ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int n_intv, const Seed *occ, int n_occ,
                              int *next, Chain *ctmp, BtNode *nodes, int cap_nodes, int *iscr, Chain *cout, Seed *sout, int sout_base)
@@ -206,42 +206,55 @@ ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int 
 		}
 	}
 	if (n_ch == 0) return 0;
-	int *ord = iscr, *kept_idx = iscr + n_occ, *qb_ = iscr + 2 * n_occ, *qe_ = iscr + 3 * n_occ; // iscr: 4 * n_occ ints
+	int *ord = iscr, *kept_idx = iscr + n_occ; // iscr: 7 * n_occ ints
+	int *qb_ = iscr + 2 * n_occ, *qe_ = iscr + 3 * n_occ, *w_ = iscr + 4 * n_occ, *alt_ = iscr + 5 * n_occ, *first_ = iscr + 6 * n_occ; // by rank in `ord`
 	int n = bt_traverse(bt, ord); // chains in key order = the array mem_chain returns
 	// mem_chain_flt (bwamem.c:327-385)
 	for (int i = 0; i < n; ++i) { Chain &c = ctmp[ord[i]]; c.first = -1; c.kept = 0; c.w = chain_weight(c, occ, next); }
 	WeightGt gt; gt.c = ctmp;
 	ks_introsort(n, ord, gt);
+	// The filter compares every chain with every chain kept so far: quadratic for a read in a high-copy repeat (all its chains cover
+	// the same query span and weigh the same, so nothing is dropped early).  What a comparison looks at -- query span (chn_beg /
+	// chn_end, bwamem.c:325-326), weight, is_alt, `first` -- is laid out by rank once, and the kept chains are visited four at a
+	// time: their loads do not depend on each other, the verdicts are then taken in order exactly as the reference's loop would.
+	for (int i = 0; i < n; ++i) {
+		const Chain &c = ctmp[ord[i]];
+		qb_[i] = occ[c.head].qbeg; qe_[i] = occ[c.tail].qbeg + occ[c.tail].len; w_[i] = c.w; alt_[i] = c.is_alt; first_[i] = -1;
+	}
 	int n_kept = 0;
 	ctmp[ord[0]].kept = 3;
 	kept_idx[n_kept++] = 0;
-	for (int i = 0; i < n; ++i) { const Chain &c = ctmp[ord[i]]; qb_[i] = occ[c.head].qbeg; qe_[i] = occ[c.tail].qbeg + occ[c.tail].len; } // chn_beg / chn_end (bwamem.c:325-326)
 	for (int i = 1; i < n; ++i) {
-		Chain &ci = ctmp[ord[i]];
-		const int bi = qb_[i], ei = qe_[i], wi = ci.w, alt_i = ci.is_alt;
-		int large_ovlp = 0, k;
-		for (k = 0; k < n_kept; ++k) {
-			const int kj = kept_idx[k];
-			const int bj = qb_[kj], ej = qe_[kj];
-			const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
-			if (e_min > b_max) {
-				Chain &cj = ctmp[ord[kj]];
-				if (!cj.is_alt || alt_i) {
-					const int li = ei - bi, lj = ej - bj;
+		const int bi = qb_[i], ei = qe_[i], wi = w_[i], alt_i = alt_[i];
+		int large_ovlp = 0;
+		bool dropped = false;
+		for (int k0 = 0; k0 < n_kept && !dropped; k0 += 4) {
+			int kj[4], bj[4], ej[4], wj[4], aj[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) kj[u] = kept_idx[k0 + u < n_kept ? k0 + u : n_kept - 1];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { bj[u] = qb_[kj[u]]; ej[u] = qe_[kj[u]]; wj[u] = w_[kj[u]]; aj[u] = alt_[kj[u]]; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				if (dropped || k0 + u >= n_kept) continue;
+				const int b_max = bj[u] > bi ? bj[u] : bi, e_min = ej[u] < ei ? ej[u] : ei;
+				if (e_min > b_max && (!aj[u] || alt_i)) {
+					const int li = ei - bi, lj = ej[u] - bj[u];
 					const int min_l = li < lj ? li : lj;
 					if ((float)(e_min - b_max) >= min_l * OPT_MASK_LEVEL && min_l < OPT_MAX_CHAIN_GAP) {
 						large_ovlp = 1;
-						if (cj.first < 0) cj.first = i;
-						if ((float)wi < cj.w * OPT_DROP_RATIO && cj.w - wi >= OPT_MIN_SEED_LEN << 1) break;
+						if (first_[kj[u]] < 0) first_[kj[u]] = i;
+						if ((float)wi < wj[u] * OPT_DROP_RATIO && wj[u] - wi >= OPT_MIN_SEED_LEN << 1) dropped = true;
 					}
 				}
 			}
 		}
-		if (k == n_kept) { kept_idx[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
+		if (!dropped) { kept_idx[n_kept++] = i; ctmp[ord[i]].kept = large_ovlp ? 2 : 3; }
 	}
 	for (int i = 0; i < n_kept; ++i) {
-		const Chain &c = ctmp[ord[kept_idx[i]]];
-		if (c.first >= 0) ctmp[ord[c.first]].kept = 1;
+		const int f = first_[kept_idx[i]];
+		ctmp[ord[kept_idx[i]]].first = f;
+		if (f >= 0) ctmp[ord[f]].kept = 1;
 	}
 	// max_chain_extend = 1<<30 never triggers (bwamem.c:373-378); compact the survivors with their seeds in list order
 	int m = 0, so = 0;

@@ -385,7 +385,7 @@ ARX_DEVI bool regs_redundant(const Reg &p, const Reg &q)
 // region meets b the same way.  Regions of one contig are contiguous in `re` order, which makes the set of regions b meets
 // independent of the others.  Returns the new length, or -1 when the outcome would depend on how introsort orders equal
 // keys (a region with the same `re`, or the same (score, rb, qb)): the caller then takes the general path.
-ARX_DEV int dedup_insert(const Reg &b_in, Reg *ma, int n, Reg *tmp, int *idx)
+ARX_DEV int dedup_insert_long(const Reg &b_in, Reg *ma, int n, Reg *tmp, int *idx)
 {
 	Reg b = b_in;
 	b.n_comp = 1;
@@ -439,6 +439,103 @@ ARX_DEV int dedup_insert(const Reg &b_in, Reg *ma, int n, Reg *tmp, int *idx)
 		ma[at] = b;
 		return n + 1;
 	}
+	int m = 0;
+	bool placed = b_gone;
+	for (int i = 0; i < n; ++i) {
+		const Reg &x = ma[i];
+		if (!(x.qe > x.qb)) continue;
+		if (!placed && !(x.score > b.score || (x.score == b.score && (x.rb < b.rb || (x.rb == b.rb && x.qb < b.qb))))) { tmp[m++] = b; placed = true; }
+		tmp[m] = x; tmp[m].n_comp = 1; ++m;
+	}
+	if (!placed) tmp[m++] = b;
+	for (int i = 0; i < m; ++i) ma[i] = tmp[i];
+	return m;
+}
+
+// The same, for lists of up to 256 regions, arranged so that one thread keeps several loads in flight: the scan reads only the first
+// 32 bytes of a region (rb, re, qb, qe, rid, score), four regions per round trip, and notes in bit masks which regions are redundant
+// with b on either side; the order-dependent part of the reference's loop (who is looked at first, where it stops) is settled afterwards
+// from the masks: on the earlier side b meets regions by decreasing `re` and dies at the first redundant one that scores higher (the
+// "stopper"), the redundant ones met before it go; on the later side by increasing `re`, the stopper being the first redundant region
+// that does not score lower.  Equal `re` keeps list order on both sides, as the insertion sorts of dedup_insert_long() do.
+struct RegHead { int64_t rb, re; int32_t qb, qe, rid, score; }; // the first 32 bytes of Reg
+ARX_DEV int dedup_insert(const Reg &b_in, Reg *ma, int n, Reg *tmp, int *idx)
+{
+	if (n > 256) return dedup_insert_long(b_in, ma, n, tmp, idx);
+	Reg b = b_in;
+	b.n_comp = 1;
+	uint64_t E[4] = {0, 0, 0, 0}, L[4] = {0, 0, 0, 0};
+	int s1 = -1, s2 = -1, at = n; // stoppers (earlier / later side), first region that does not sort before b
+	int64_t s1_re = 0, s2_re = 0;
+	for (int j0 = 0; j0 < n; j0 += 4) {
+		RegHead h[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) h[u] = *(const RegHead *)(ma + (j0 + u < n ? j0 + u : n - 1));
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int j = j0 + u;
+			if (j >= n) continue;
+			const RegHead &q = h[u];
+			if (q.re == b.re) return -1;
+			if (q.score == b.score && q.rb == b.rb && q.qb == b.qb) return -1;
+			if (j < at && !(q.score > b.score || (q.score == b.score && (q.rb < b.rb || (q.rb == b.rb && q.qb < b.qb))))) at = j;
+			if (q.rid != b.rid) continue;
+			if (q.re < b.re) {
+				if (!(b.rb < q.re + OPT_MAX_CHAIN_GAP)) continue;
+				// regs_redundant(p = b, q)
+				const int64_t orr = q.re - b.rb, oq = q.qb < b.qb ? q.qe - b.qb : b.qe - q.qb;
+				const int64_t mr = q.re - q.rb < b.re - b.rb ? q.re - q.rb : b.re - b.rb, mq = q.qe - q.qb < b.qe - b.qb ? q.qe - q.qb : b.qe - b.qb;
+				if (!((float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq)) continue;
+				E[j >> 6] |= 1ull << (j & 63);
+				if (b.score < q.score && (s1 < 0 || q.re > s1_re)) { s1 = j; s1_re = q.re; } // equal re: the smaller index stays
+			} else {
+				if (!(q.rb < b.re + OPT_MAX_CHAIN_GAP)) continue;
+				// regs_redundant(p = q, q = b)
+				const int64_t orr = b.re - q.rb, oq = b.qb < q.qb ? b.qe - q.qb : q.qe - b.qb;
+				const int64_t mr = b.re - b.rb < q.re - q.rb ? b.re - b.rb : q.re - q.rb, mq = b.qe - b.qb < q.qe - q.qb ? b.qe - b.qb : q.qe - q.qb;
+				if (!((float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq)) continue;
+				L[j >> 6] |= 1ull << (j & 63);
+				if (!(q.score < b.score) && (s2 < 0 || q.re < s2_re)) { s2 = j; s2_re = q.re; }
+			}
+		}
+	}
+	bool b_gone = s1 >= 0;
+	uint64_t G[4] = {0, 0, 0, 0}; // regions that go
+	int n_gone = 0;
+	if (E[0] | E[1] | E[2] | E[3]) {
+		for (int wd = 0; wd < 4; ++wd)
+			for (uint64_t m = E[wd]; m; m &= m - 1) {
+				const int j = wd * 64 + __builtin_ctzll(m);
+				if (s1 >= 0) { const int64_t re = ma[j].re; if (!(re > s1_re || (re == s1_re && j < s1))) continue; }
+				G[wd] |= 1ull << (j & 63); ++n_gone;
+			}
+	}
+	if (!b_gone) {
+		b_gone = s2 >= 0;
+		if (L[0] | L[1] | L[2] | L[3]) {
+			for (int wd = 0; wd < 4; ++wd)
+				for (uint64_t m = L[wd]; m; m &= m - 1) {
+					const int j = wd * 64 + __builtin_ctzll(m);
+					if (s2 >= 0) { const int64_t re = ma[j].re; if (!(re < s2_re || (re == s2_re && j < s2))) continue; }
+					G[wd] |= 1ull << (j & 63); ++n_gone;
+				}
+		}
+	}
+	if (n_gone == 0) {
+		for (int i = 0; i < n; ++i) ma[i].n_comp = 1;
+		if (b_gone) return n;
+		// make room at `at`: four regions per round trip, from the top
+		int i = n;
+		for (; i - 4 >= at; i -= 4) {
+			const Reg r0 = ma[i - 1], r1 = ma[i - 2], r2 = ma[i - 3], r3 = ma[i - 4];
+			ma[i] = r0; ma[i - 1] = r1; ma[i - 2] = r2; ma[i - 3] = r3;
+		}
+		for (; i > at; --i) ma[i] = ma[i - 1];
+		ma[at] = b;
+		return n + 1;
+	}
+	for (int wd = 0; wd < 4; ++wd)
+		for (uint64_t m = G[wd]; m; m &= m - 1) { Reg &x = ma[wd * 64 + __builtin_ctzll(m)]; x.qe = x.qb; } // as the reference marks them
 	int m = 0;
 	bool placed = b_gone;
 	for (int i = 0; i < n; ++i) {

@@ -177,7 +177,7 @@ struct KChain {
 		const int g0 = occ_off[r], n = occ_off[r + 1] - g0;
 		const int node0 = g0 / 3 + 4 * r, node1 = occ_off[r + 1] / 3 + 4 * (r + 1);
 		int m = chain_and_filter(ix, lens[r], intv + (size_t)r * CAP_INTV, n_intv[r], occ_seed + g0, n, next + g0, ctmp + g0,
-		                         nodes + node0, node1 - node0, iscr + 4 * (size_t)g0, cout + g0, sout + g0, g0);
+		                         nodes + node0, node1 - node0, iscr + 7 * (size_t)g0, cout + g0, sout + g0, g0);
 		if (m < 0) { raise_err(err, ERR_POOL_OVERFLOW); m = 0; }
 		n_chain[r] = m;
 	}
@@ -509,7 +509,7 @@ public:
 	{
 		const int R = b.n_reads; const size_t T = (size_t)w.T + 1;
 		w.next = rt.template alloc<int32_t>(T); w.ctmp = rt.template alloc<Chain>(T); w.cout = rt.template alloc<Chain>(T);
-		w.nodes = rt.template alloc<BtNode>(T / 3 + 4 * (size_t)R + 8); w.iscr = rt.template alloc<int32_t>(4 * T); w.sout = rt.template alloc<Seed>(T);
+		w.nodes = rt.template alloc<BtNode>(T / 3 + 4 * (size_t)R + 8); w.iscr = rt.template alloc<int32_t>(7 * T + 8); w.sout = rt.template alloc<Seed>(T);
 		w.n_chain = rt.template alloc<int32_t>(R + 1);
 		KChain k{ix, b.lens, w.intv, w.n_intv, w.occ_off, w.occ_seed, w.next, w.ctmp, w.nodes, w.iscr, w.cout, w.sout, w.n_chain, w.err};
 		rt.launch_wide("chain", R, k);

@@ -162,3 +162,46 @@ ARX_DEFINE_C_API(arx::SimRT)
 
 // test entry: the rescue pre-filter alone (tests/test_sw_prefilter.py checks it against the oracle's ksw_align2)
 extern "C" int arx_test_sw_prefilter(const uint8_t *q, int qlen, const uint8_t *t, int tlen) { return arx::sw_prefilter_serial(q, qlen, t, tlen) ? 1 : 0; }
+
+// test entry: dedup_insert() (the one-scan insertion into a list that is a fixed point of mem_sort_dedup_patch) against the general
+// path on random lists built to collide -- clustered regions on a few contigs with overlapping spans, so that both sides of the
+// inserted region hold redundant neighbours, stoppers and survivors.  Returns the number of cases compared (< 0: first mismatch).
+extern "C" long arx_test_dedup_insert(unsigned seed, int iters, long *n_fast, long *n_gone_cases, long *n_b_gone)
+{
+	using namespace arx;
+	uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1);
+	auto rnd = [&](int m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (int)(x % (uint64_t)m); };
+	auto make = [&](Reg &r) {
+		r = Reg();
+		r.rid = rnd(3);
+		const int64_t base = 100000 * r.rid + 200 * rnd(6);           // a handful of clusters
+		r.rb = base + rnd(40); r.re = r.rb + 100 + rnd(60);
+		r.qb = rnd(30); r.qe = r.qb + 100 + rnd(20);
+		r.score = 60 + rnd(60); r.truesc = r.score; r.secondary = -1; r.n_comp = 1;
+	};
+	IndexView ix = IndexView();
+	long cases = 0;
+	*n_fast = *n_gone_cases = *n_b_gone = 0;
+	for (int it = 0; it < iters; ++it) {
+		const int n0 = 2 + rnd(it % 7 == 0 ? 300 : 40);
+		std::vector<Reg> a(n0 + 2), tmp(n0 + 2), chk;
+		std::vector<int> idx(n0 + 2);
+		for (int i = 0; i < n0; ++i) make(a[i]);
+		int n = sort_dedup_patch(ix, 0, n0, a.data(), tmp.data(), idx.data(), 0);   // a fixed point of the pass
+		if (n < 2) continue;
+		Reg b; make(b);
+		if (rnd(3) == 0) { const Reg &q = a[rnd(n)]; b.rid = q.rid; b.rb = q.rb + rnd(5) - 2; b.re = q.re + rnd(5) - 2; b.qb = q.qb; b.qe = q.qe; b.score = q.score + rnd(21) - 10; }
+		chk.assign(a.begin(), a.begin() + n);
+		{ int at = 0; while (at < n && !(chk[at].score < b.score)) ++at; chk.insert(chk.begin() + at, b); }
+		std::vector<Reg> t2(n + 2); std::vector<int> i2(n + 2);
+		const int m2 = sort_dedup_patch(ix, 0, n + 1, chk.data(), t2.data(), i2.data(), 0);
+		a.resize(n + 2); tmp.resize(n + 2); idx.resize(n + 2);
+		const int m = dedup_insert(b, a.data(), n, tmp.data(), idx.data());
+		++cases;
+		if (m < 0) continue; // tie: the caller takes the general path
+		++*n_fast;
+		if (m != n + 1) { if (m == n) ++*n_b_gone; else ++*n_gone_cases; }
+		if (m != m2 || memcmp(a.data(), chk.data(), sizeof(Reg) * (size_t)m)) return -cases;
+	}
+	return cases;
+}

@@ -136,3 +136,17 @@ def test_close_frees_batches_left_alive(built):
         ref.close()
         assert b.h is None
         del b
+
+
+def test_dedup_insert_equals_the_general_pass_on_colliding_lists():
+    """dedup_insert() (dev_regs.h: what a rescued region costs to merge into a clean list) against mem_sort_dedup_patch's restatement on
+    random lists built so that redundant neighbours, stoppers on either side and survivors all occur (also lists beyond 256 regions:
+    the serial variant)."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    lib = C.CDLL(SIM)
+    lib.arx_test_dedup_insert.restype = C.c_long
+    nf, ng, nb = C.c_long(), C.c_long(), C.c_long()
+    cases = lib.arx_test_dedup_insert(5, 20000, C.byref(nf), C.byref(ng), C.byref(nb))
+    assert cases > 10000, cases                      # negative: index of the first mismatch
+    assert nf.value > 5000 and ng.value > 200 and nb.value > 200, (nf.value, ng.value, nb.value)
