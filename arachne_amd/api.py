@@ -68,6 +68,7 @@ def _load(path):
     lib.arx_backend.restype = C.c_char_p
     lib.arx_contigs.argtypes = [vp] + [vp] * 6
     lib.arx_batch_create.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
+    lib.arx_batch_reset.argtypes = [vp, vp, i32, vp, vp]
     lib.arx_batch_run.argtypes = [vp, vp, i32]
     lib.arx_batch_counts.argtypes = [vp, vp, vp]
     lib.arx_batch_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -111,6 +112,30 @@ class Batch:
         ref._check(ref.lib.arx_batch_create(ref.h, self.n_reads, bases.ctypes.data, lens.ctypes.data, C.byref(h)))
         self.h = h
         ref._batches.add(self)
+
+    def reset(self, seqs, lens):
+        """New reads into the same handle (arx_batch_reset): stream, work memory and input buffers are reused."""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        bases = np.ascontiguousarray(seqs, dtype=np.uint8).reshape(-1)
+        self.n_reads = len(lens)
+        self._keep = (bases, lens)
+        self._n_cands = 0
+        self.ref._check(self.ref.lib.arx_batch_reset(self.ref.h, self.h, self.n_reads, bases.ctypes.data, lens.ctypes.data))
+        return self
+
+    def fetch_into(self, buf):
+        """arx_batch_fetch + arx_batch_rfa_fetch into arrays the caller keeps (buf: dict with reg_off, regs, alns, cigars, cand_off, cands,
+        each at least as long as this batch needs; grown here when not): what a steady-state caller does, no allocation per batch."""
+        c = self.counts()
+        need = dict(reg_off=(self.n_reads + 1, np.int32), regs=(c["n_regs"], REG_DTYPE), alns=(c["n_regs"], ALN_DTYPE), cigars=(max(c["n_cigar"], 1), np.uint32),
+                    cand_off=(self.n_reads + 1, np.int32), cands=(self._n_cands, CAND_DTYPE))
+        for k, (n, dt) in need.items():
+            if k not in buf or len(buf[k]) < n:
+                buf[k] = np.zeros(int(n * 1.2) + 16, dtype=dt)
+        self.ref._check(self.ref.lib.arx_batch_fetch(self.ref.h, self.h, buf["reg_off"].ctypes.data, buf["regs"].ctypes.data, buf["alns"].ctypes.data, buf["cigars"].ctypes.data))
+        if self._n_cands:
+            self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, buf["cand_off"].ctypes.data, buf["cands"].ctypes.data))
+        return c
 
     def run(self, last_stage=STAGE_ALN):
         self.ref._check(self.ref.lib.arx_batch_run(self.ref.h, self.h, last_stage))

@@ -187,9 +187,23 @@ template <class RT> struct Batch {
 		Ctx *c = (Ctx *)h;                                                                                                          \
 		*out = 0;                                                                                                                   \
 		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
-		for (int i = 0; i < n_reads; ++i)                                                                                           \
-			if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; }     \
+		{ int64_t tot = 0;                                                                                                          \
+		  for (int i = 0; i < n_reads; ++i) { if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; } tot += lens[i]; } \
+		  if (tot >= ((int64_t)1 << 31) - 64) { c->set_error("batch too large: more than 2^31 bases, split the batch"); return ARX_E_TOO_LARGE; } } \
 		ARX_TRY(c, Bat *b = new Bat(c); b->rt.bind(); b->db = b->pipe.upload(bases, lens, n_reads); b->lens_host.assign(lens, lens + n_reads); *out = (arx_batch *)b;) \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_reset(arx_ctx *h, arx_batch *bh, int32_t n_reads, const uint8_t *bases, const int32_t *lens)                      \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
+		{ int64_t tot = 0;                                                                                                          \
+		  for (int i = 0; i < n_reads; ++i) { if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; } tot += lens[i]; } \
+		  if (tot >= ((int64_t)1 << 31) - 64) { c->set_error("batch too large: more than 2^31 bases, split the batch"); return ARX_E_TOO_LARGE; } } \
+		ARX_TRY(c, b->rt.bind();                                                                                                    \
+			b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; b->rfa_marked = false;                      \
+			b->rfa = arx::RfaResult(); b->post = arx::PostResult();                                                                 \
+			b->pipe.upload_into(b->db, bases, lens, n_reads); b->lens_host.assign(lens, lens + n_reads);)                           \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_run(arx_ctx *h, arx_batch *bh, int32_t last_stage)                                                                \
@@ -240,6 +254,7 @@ template <class RT> struct Batch {
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (!b->work.alns) { c->set_error("arx_batch_rfa before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }                 \
 		if (n_barcodes <= 0 || bc_pair_off[0] != 0 || 2 * bc_pair_off[n_barcodes] != b->db.n_reads) { c->set_error("barcode offsets must cover the batch"); return ARX_E_ARG; } \
+		for (int i = 0; i < n_barcodes; ++i) if (bc_pair_off[i + 1] < bc_pair_off[i]) { c->set_error("barcode offsets must not decrease"); return ARX_E_ARG; } \
 		ARX_TRY(c, b->rt.bind(); b->rt.set_timing(c->timing);                                                                       \
 			if (b->rfa_marked) b->rt.arena_rewind(b->rfa_mark); else { b->rfa_mark = b->rt.arena_mark(); b->rfa_marked = true; }    \
 			arx::RfaStage<RT>::run(b->pipe, b->db, b->work, n_barcodes, bc_pair_off, do_rfa, penalty, cen_start, cen_end, b->lens_host.data(), b->rfa); \

@@ -74,6 +74,7 @@ struct HipRT {
 		if (scan_tmp) hipFree(scan_tmp);
 		if (d_total) hipFree(d_total);
 		if (pinned) (void)hipHostFree(pinned);
+		if (stage_buf) (void)hipHostFree(stage_buf);
 		for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 		for (auto e : free_events) (void)hipEventDestroy(e);
 		if (stream) hipStreamDestroy(stream);
@@ -111,6 +112,20 @@ struct HipRT {
 		ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream));
 		ARX_HIP_CHECK(hipStreamSynchronize(stream));
 	}
+	// staging for uploads: pinned host memory owned by the runtime, grown on demand.  stage() waits for the copies of the previous
+	// use (the stream has long passed them when a batch is reset after its results were fetched); h2d_staged() only enqueues.
+	void *stage_buf = 0; size_t stage_cap = 0;
+	void *stage(size_t bytes)
+	{
+		ARX_HIP_CHECK(hipStreamSynchronize(stream));
+		if (bytes > stage_cap) {
+			if (stage_buf) (void)hipHostFree(stage_buf);
+			stage_buf = 0; stage_cap = bytes + bytes / 8 + 4096;
+			ARX_HIP_CHECK(hipHostMalloc(&stage_buf, stage_cap, hipHostMallocDefault));
+		}
+		return stage_buf;
+	}
+	void h2d_staged(void *d, const void *staged, size_t bytes) { if (bytes) ARX_HIP_CHECK(hipMemcpyAsync(d, staged, bytes, hipMemcpyHostToDevice, stream)); }
 	void memset0(void *d, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, 0, bytes, stream)); }
 	void memset_bytes(void *d, int v, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, v, bytes, stream)); }
 	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }

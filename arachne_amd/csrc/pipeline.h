@@ -406,23 +406,38 @@ public:
 	int seed_pool_per_read = getenv("ARX_SEED_POOL") ? atoi(getenv("ARX_SEED_POOL")) : 384; // interval-pool entries per read (3 per forward-list entry); an overflow is reported, never silent
 	explicit Pipeline(RT &rt_, const IndexView &ix_) : rt(rt_), ix(ix_) {}
 
-	// device-resident input of one batch
-	struct DeviceBatch { uint8_t *bases = 0; int32_t *base_off = 0, *lens = 0; int n_reads = 0; int64_t n_bases = 0; int max_len = 0; };
+	// device-resident input of one batch; the buffers are kept by the handle and reused by arx_batch_reset (cap_*: what they hold)
+	struct DeviceBatch { uint8_t *bases = 0; int32_t *base_off = 0, *lens = 0; int n_reads = 0; int64_t n_bases = 0; int max_len = 0; int64_t cap_bases = 0; int cap_reads = 0; };
 
+	// Reads go to HBM through the runtime's staging (pinned host memory on the GPU, one async copy per array on the batch's stream).
+	// An existing batch keeps its buffers when the new reads fit: a steady-state caller allocates nothing (the reference recycles
+	// its buffers per work unit the same way, aligner.go:234 ReturnBuffer, gobwa.go:107-126 Arena).
+	void upload_into(DeviceBatch &b, const uint8_t *bases, const int32_t *lens, int n_reads)
+	{
+		int64_t tot = 0; int mx = 0;
+		for (int i = 0; i < n_reads; ++i) { tot += lens[i]; if (lens[i] > mx) mx = lens[i]; }
+		if (tot + 16 > b.cap_bases) { rt.pfree(b.bases); b.cap_bases = tot + tot / 8 + 64; b.bases = rt.template palloc<uint8_t>((size_t)b.cap_bases); }
+		if (n_reads + 1 > b.cap_reads) {
+			rt.pfree(b.base_off); rt.pfree(b.lens);
+			b.cap_reads = n_reads + n_reads / 8 + 8;
+			b.base_off = rt.template palloc<int32_t>((size_t)b.cap_reads); b.lens = rt.template palloc<int32_t>((size_t)b.cap_reads);
+		}
+		b.n_reads = n_reads; b.n_bases = tot; b.max_len = mx;
+		uint8_t *st = (uint8_t *)rt.stage((size_t)tot + 8 * ((size_t)n_reads + 2));
+		int32_t *st_off = (int32_t *)(st + (((size_t)tot + 7) & ~(size_t)7)), *st_len = st_off + n_reads + 1;
+		memcpy(st, bases, (size_t)tot);
+		int64_t run = 0;
+		for (int i = 0; i < n_reads; ++i) { st_off[i] = (int32_t)run; run += lens[i]; }
+		st_off[n_reads] = (int32_t)run;
+		memcpy(st_len, lens, sizeof(int32_t) * (size_t)n_reads);
+		rt.h2d_staged(b.bases, st, (size_t)tot);
+		rt.h2d_staged(b.base_off, st_off, sizeof(int32_t) * ((size_t)n_reads + 1));
+		rt.h2d_staged(b.lens, st_len, sizeof(int32_t) * (size_t)n_reads);
+	}
 	DeviceBatch upload(const uint8_t *bases, const int32_t *lens, int n_reads)
 	{
 		DeviceBatch b;
-		std::vector<int32_t> off(n_reads + 1);
-		int64_t tot = 0; int mx = 0;
-		for (int i = 0; i < n_reads; ++i) { off[i] = (int32_t)tot; tot += lens[i]; if (lens[i] > mx) mx = lens[i]; }
-		off[n_reads] = (int32_t)tot;
-		b.n_reads = n_reads; b.n_bases = tot; b.max_len = mx;
-		b.bases = rt.template palloc<uint8_t>(tot + 16);
-		b.base_off = rt.template palloc<int32_t>(n_reads + 1);
-		b.lens = rt.template palloc<int32_t>(n_reads + 1);
-		rt.h2d(b.bases, bases, tot);
-		rt.h2d(b.base_off, off.data(), sizeof(int32_t) * (n_reads + 1));
-		rt.h2d(b.lens, lens, sizeof(int32_t) * n_reads);
+		upload_into(b, bases, lens, n_reads);
 		return b;
 	}
 	void release(DeviceBatch &b) { rt.pfree(b.bases); rt.pfree(b.base_off); rt.pfree(b.lens); b = DeviceBatch(); }

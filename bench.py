@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
     ap.add_argument("--post", action="store_true", help="also run the passes between placement and the BAM records in the step (CIGAR walk with "
                     "mismatch locations, markDuplicates, split reads: SURVEY.md s8f-3)")
+    ap.add_argument("--boundary-steps", type=int, default=3, help="extra steps timed boundary to boundary (host reads in through arx_batch_reset, "
+                    "results out through arx_batch_fetch + arx_batch_rfa_fetch into reused host arrays); 0: skip.  Reported under `boundary`, never as `value`")
     ap.add_argument("--depth", type=int, default=1, help="batch handles per chunk of the read set (steps in flight)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
@@ -273,6 +275,8 @@ def main():
                 end += 1
             p0, p1 = int(po[start]), int(po[end])
             b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1])
+            b.host = (np.ascontiguousarray(rs.seqs[2 * p0:2 * p1]).reshape(-1), np.ascontiguousarray(rs.lens[2 * p0:2 * p1]))
+            b.out = {}
             b.bc_pair_off = (po[start:end + 1] - po[start]).astype(np.int64)
             b.do_rfa = np.array([api.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(start, end)], dtype=np.uint8)
             bs.append(b)
@@ -288,8 +292,8 @@ def main():
 
     import threading
 
-    def run_steps(n_steps):
-        """n_steps passes over the whole read set.  Every batch runs start to end on its own stream and host thread; the seeding
+    def run_steps(n_steps, boundary=False):
+        """n_steps passes over the whole read set (boundary: every pass hands the reads over from host memory and takes the results back).  Every batch runs start to end on its own stream and host thread; the seeding
         stages go one after the other (batch i of a step after batch i - 1, the first batch of the next step after the last of
         this one), so that the latency-bound seeding kernels share the chip with the VALU-bound DP kernels of the batches ahead
         of them rather than with each other.  Their HIP-event times in the timed region are still co-running times; the same
@@ -323,6 +327,8 @@ def main():
                             if args.post:
                                 b.post(fetch=False)
                     continue
+                if boundary:
+                    b.reset(*b.host)                      # reads come from host memory: pinned staging + async copies on the batch's stream
                 if i > 0:
                     wait_for(seeded[s_][i - 1])
                 elif s_ > 0:
@@ -334,6 +340,8 @@ def main():
                     b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
                     if args.post:
                         b.post(fetch=False)
+                if boundary:
+                    b.fetch_into(b.out)                   # regions, alignment records, CIGARs, placed candidates with MAPQ back in host memory
         list(pool.map(worker, range(nb * len(sets))))
 
     run_steps(args.warmup)
@@ -350,6 +358,21 @@ def main():
         dt = float(tt.item())
     ktimes = ref.kernel_times()
     counts = [b.counts() for b in batches]
+    # the same steps boundary to boundary: host arrays in (arx_batch_reset), host arrays out (arx_batch_fetch, arx_batch_rfa_fetch)
+    boundary = None
+    if args.boundary_steps > 0 and args.stagger:
+        ref.kernel_times_reset(False)
+        run_steps(1, boundary=True)                       # sizes the reused host arrays and the staging
+        barrier()
+        tb = time.time()
+        run_steps(args.boundary_steps, boundary=True)
+        barrier()
+        boundary = time.time() - tb
+        if dist is not None:
+            import torch
+            tt = torch.tensor([boundary], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            boundary = float(tt.item())
     # the seeding kernel alone on the chip, same inputs, outside the timed region
     ref.kernel_times_reset(True)
     for b in batches:
@@ -378,6 +401,13 @@ def main():
                                parallelism=f"barcode-sharded x{world}"))
         out["per_rank"] = per_rank
         out["setup_s"] = setup
+        if boundary:
+            out_bytes = sum(int(c["n_regs"]) * (88 + 48) + int(c["n_cigar"]) * 4 + int(c["n_reads"]) * 8 for c in counts) + sum(b._n_cands for b in batches) * 96
+            out["boundary"] = dict(value=pairs_per_step * args.boundary_steps / boundary, unit="paired reads/s", steps=args.boundary_steps,
+                                   ms_per_step=1000.0 * boundary / args.boundary_steps,
+                                   host_bytes_in_per_pair=round(float(rs.lens.sum()) / rs.n_pairs + 8, 1), host_bytes_out_per_pair=round(out_bytes / rs.n_pairs, 1),
+                                   note="same steps timed from host arrays in (arx_batch_reset: pinned staging, async H2D on the batch's stream, handle and work memory "
+                                        "reused) to host arrays out (arx_batch_fetch + arx_batch_rfa_fetch into arrays the caller reuses); PCIe-inclusive, never `value`")
         # where the FM-index lives decides what the seeding kernels are bound by: a table under 256 MiB stays in the Infinity Cache
         occ_bytes = index_bytes["bwt"]
         in_hbm = occ_bytes > INFINITY_CACHE_BYTES

@@ -67,6 +67,10 @@ int arx_contigs(arx_ctx *ctx, int32_t *n, const char *const **names, const int64
 /* bases: concatenated reads as codes 0..4 (A,C,G,T,N); lens[n_reads]; read 2i and 2i+1 are mates (either may be empty).
  * Reads of one barcode are contiguous; barcode boundaries do not matter to this stage (pairs are independent). */
 int arx_batch_create(arx_ctx *ctx, int32_t n_reads, const uint8_t *bases, const int32_t *lens, arx_batch **out);
+/* Replaces the reads of an existing batch: same stream, same work memory, same input buffers when the new reads fit -- a caller in
+ * steady state allocates nothing (what the reference does with its per-work-unit buffers: aligner.go:234 ReturnBuffer, gobwa.go:107-126
+ * Arena).  Results of the previous run are gone; the uploads are asynchronous on the batch's stream (pinned staging inside). */
+int arx_batch_reset(arx_ctx *ctx, arx_batch *b, int32_t n_reads, const uint8_t *bases, const int32_t *lens);
 /* Runs the stages up to last_stage.  Stages already done are kept: run(ARX_STAGE_SEED) followed by run(ARX_STAGE_ALN) resumes after
  * seeding; asking for a stage that is already done (or an earlier one) restarts the batch from its reads.  All work memory of the
  * batch is reused by the next run, so results (arx_batch_fetch, arx_batch_rfa_fetch) must be fetched before it. */

@@ -150,3 +150,33 @@ def test_dedup_insert_equals_the_general_pass_on_colliding_lists():
     cases = lib.arx_test_dedup_insert(5, 20000, C.byref(nf), C.byref(ng), C.byref(nb))
     assert cases > 10000, cases                      # negative: index of the first mismatch
     assert nf.value > 5000 and ng.value > 200 and nb.value > 200, (nf.value, ng.value, nb.value)
+
+
+def test_batch_reset_reuses_the_handle_and_matches_a_fresh_batch():
+    """arx_batch_reset: new reads into an existing handle (larger, then smaller than the first set) give what a fresh batch gives."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    z = np.load(os.path.join(workloads.GOLDEN_DIR, "bwa_path_v1.npz"))
+    prefix = workloads.unpack_index(z, tempfile.mkdtemp(prefix="arx_reset_"))
+    ref = api.Reference(prefix, lib_path=SIM)
+    reads, lens = z["reads"], z["lens"]
+    b = ref.batch(reads[:100], lens[:100]).run()
+    first = b.fetch()
+    for lo, hi in ((100, 500), (40, 60), (0, 100)):
+        fresh = ref.mem_mate_sw(reads[lo:hi], lens[lo:hi])
+        again = b.reset(reads[lo:hi], lens[lo:hi]).run().fetch()
+        for k in ("reg_off", "regs", "alns", "cigars"):
+            assert np.array_equal(fresh[k], again[k]), (lo, hi, k)
+        po = [0, (hi - lo) // 4, (hi - lo) // 2]
+        c1 = b.rfa(po, [True, True])
+        b2 = ref.batch(reads[lo:hi], lens[lo:hi]).run()
+        c2 = b2.rfa(po, [True, True])
+        assert np.array_equal(c1["cands"], c2["cands"]) and np.array_equal(c1["cand_off"], c2["cand_off"])
+        buf = {}
+        b.fetch_into(buf)
+        assert np.array_equal(buf["regs"][:len(again["regs"])], again["regs"]) and np.array_equal(buf["cands"][:len(c1["cands"])], c1["cands"])
+        b2.free()
+    assert np.array_equal(first["regs"], b.reset(reads[:100], lens[:100]).run().fetch()["regs"])
+    with pytest.raises(api.ArachneError):
+        b.reset(reads[:3], lens[:3])          # odd number of reads
+    b.free()
+    ref.close()
