@@ -62,12 +62,22 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def prepare_index(cache, name, lens, seed, families, rank, barrier, setup):
-    """Synthetic genome + index (built by the product's own `bwa index` equivalent: suffix sorting in HBM), cached on disk."""
+def prepare_index(cache, name, lens, seed, families, rank, barrier, setup, in_child=False):
+    """Synthetic genome + index (built by the product's own `bwa index` equivalent: suffix sorting in HBM), cached on disk.
+    The work is done by a child process (bench.py --prepare-only): a process that has synthesised a 3 GB genome and sorted 6.2 G
+    suffixes through 125 GB of HBM runs the timed region ~25 % slower afterwards (host-side round trips of the stage loops take longer;
+    measured in round 2) -- the measuring process stays clean."""
     from arachne_amd import api, synth
     total = int(sum(lens))
     prefix = os.path.join(cache, f"{name}_{total}.fa")
     done = prefix + ".done"
+    if rank == 0 and not os.path.exists(done) and not in_child:
+        import subprocess
+        os.makedirs(cache, exist_ok=True)
+        spec = prefix + ".spec.json"
+        json.dump(dict(cache=cache, name=name, lens=[int(x) for x in lens], seed=int(seed), families=families), open(spec, "w"))
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--prepare-only", spec])
+        setup.update(json.load(open(prefix + ".setup.json")))
     if rank == 0 and not os.path.exists(done):
         os.makedirs(cache, exist_ok=True)
         t = time.time()
@@ -86,6 +96,7 @@ def prepare_index(cache, name, lens, seed, families, rank, barrier, setup):
         log(f"index built in {time.time() - t:.1f}s (arx_index_build: FASTA -> .pac/.ann/.amb on the host, BWT + SA in HBM)")
         if total > 500_000_000:
             os.remove(prefix)          # the codes are kept as .npy; the FASTA of a GRCh38-size genome is 3 GB
+        json.dump(setup, open(prefix + ".setup.json", "w"))
         open(done, "w").write("ok")
     barrier()
     return prefix
@@ -188,6 +199,11 @@ def algorithmic_bytes(prefix, rs, n_sample):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--prepare-only":   # the child of prepare_index()
+        sp = json.load(open(sys.argv[2]))
+        fam = [tuple(f) for f in sp["families"]] if sp["families"] is not None else None
+        prepare_index(sp["cache"], sp["name"], sp["lens"], sp["seed"], fam, 0, lambda: None, {}, in_child=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
