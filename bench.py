@@ -221,6 +221,9 @@ def main():
                     "mismatch locations, markDuplicates, split reads: SURVEY.md s8f-3)")
     ap.add_argument("--boundary-steps", type=int, default=3, help="extra steps timed boundary to boundary (host reads in through arx_batch_reset, "
                     "results out through arx_batch_fetch + arx_batch_rfa_fetch into reused host arrays); 0: skip.  Reported under `boundary`, never as `value`")
+    ap.add_argument("--scatter-steps", type=int, default=0, help="N > 1: extra steps run as SURVEY.md s8e's dataflow -- rank 0 owns every rank's barcodes, assigns whole "
+                    "barcodes by pair count (LPT), scatters the packed batches and gathers the result slabs over torch.distributed point-to-point (RCCL / xGMI) "
+                    "inside the timed steps; reported under `scatter_gather` (an ingest rank cannot feed 8 GPUs at kernel rate: see DESIGN.md s6)")
     ap.add_argument("--depth", type=int, default=1, help="batch handles per chunk of the read set (steps in flight)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
@@ -396,6 +399,53 @@ def main():
     ktimes_iso = ref.kernel_times()
     ref.kernel_times_reset(False)
     # what every rank did (control plane only; the data path has no collective): pairs and regions per step
+    # SURVEY.md s8e as written: one ingest rank, LPT assignment of whole barcodes, scatter of packed batches, gather of result slabs
+    scatter_info = None
+    if args.scatter_steps > 0 and dist is not None and args.stagger:
+        from arachne_amd import shard
+        xch = shard.Exchange(dist, "cuda" if args.backend == "nccl" else "cpu")
+        nb = len(batches)
+        packed = assign = None
+        if rank == 0:   # the ingest rank holds every rank's barcodes (the same read sets the ranks synthesised for themselves)
+            genome = load_genome(prefix)
+            sets_all = [rs] + [synth.make_reads(SEED0 + 1000 * (r + 1), genome, n_barcodes, ppb, molecules_per_barcode=wl["molecules"], fast=n_barcodes * ppb > 1_500_000) for r in range(1, world)]
+            del genome
+            seqs_all = np.concatenate([x.seqs for x in sets_all]); lens_all = np.concatenate([x.lens for x in sets_all])
+            po_all = np.concatenate([[0]] + [x.pair_offsets()[1:] + i * rs.n_pairs for i, x in enumerate(sets_all)]).astype(np.int64)
+            flags_all = np.array([api.worth_running_rfa(rs.barcodes[i % len(rs.barcodes)], int(po_all[i + 1] - po_all[i])) for i in range(len(po_all) - 1)], dtype=np.uint8)
+            assign = shard.lpt_assign(np.diff(po_all), world)
+            packed = [shard.pack(seqs_all, lens_all, po_all, flags_all, a) for a in assign]
+            del sets_all, seqs_all
+
+        def scatter_step():
+            mine_p = shard.scatter_batches(xch, rank, world, packed)
+            bpo = mine_p["bc_pair_off"]; boff = np.concatenate([[0], np.cumsum(mine_p["lens"], dtype=np.int64)])
+            cuts = [int(np.searchsorted(bpo, bpo[-1] * k / nb)) for k in range(nb + 1)]   # nb device batches of whole barcodes, about equal in pairs
+            cuts[0], cuts[-1] = 0, len(bpo) - 1
+            for i, b in enumerate(batches):
+                c0, c1 = cuts[i], max(cuts[i + 1], cuts[i])
+                p0, p1 = int(bpo[c0]), int(bpo[c1])
+                b.host = (mine_p["bases"][boff[2 * p0]:boff[2 * p1]], mine_p["lens"][2 * p0:2 * p1])
+                b.bc_pair_off = (bpo[c0:c1 + 1] - bpo[c0]).astype(np.int64); b.do_rfa = mine_p["do_rfa"][c0:c1]
+            run_steps(1, boundary=True)
+            for b in batches:
+                c = b.counts()
+                slab = dict(reg_off=b.out["reg_off"][:b.n_reads + 1], regs=b.out["regs"][:c["n_regs"]], alns=b.out["alns"][:c["n_regs"]], cigars=b.out["cigars"][:c["n_cigar"]],
+                            cand_off=b.out["cand_off"][:b.n_reads + 1], cands=b.out["cands"][:b._n_cands])
+                shard.gather_results(xch, rank, world, slab)
+
+        scatter_step()
+        barrier()
+        ts = time.time()
+        for _ in range(args.scatter_steps):
+            scatter_step()
+        barrier()
+        ts = time.time() - ts
+        if rank == 0:
+            loads = [int(np.diff(po_all)[a].sum()) for a in assign]
+            scatter_info = dict(value=world * rs.n_pairs * args.scatter_steps / ts, unit="paired reads/s", steps=args.scatter_steps, ms_per_step=1000.0 * ts / args.scatter_steps,
+                                pairs_per_rank=loads, note="rank 0 owns all barcodes, LPT assignment of whole barcodes by pair count, packed batches scattered and result slabs "
+                                "gathered with torch.distributed send/recv (%s) inside every step; bounded by the ingest rank's packing and host copies, not by the GPUs" % args.backend)
     mine = dict(rank=rank, pairs=int(rs.n_pairs), regs=int(sum(c["n_regs"] for c in counts)), read_seed=SEED0 + 1000 * (rank + 1))
     per_rank = [mine]
     if dist is not None:
@@ -419,6 +469,8 @@ def main():
         out["setup_s"] = setup
         if boundary:
             out_bytes = sum(int(c["n_regs"]) * (88 + 48) + int(c["n_cigar"]) * 4 + int(c["n_reads"]) * 8 for c in counts) + sum(b._n_cands for b in batches) * 96
+            if scatter_info:
+                out["scatter_gather"] = scatter_info
             out["boundary"] = dict(value=pairs_per_step * args.boundary_steps / boundary, unit="paired reads/s", steps=args.boundary_steps,
                                    ms_per_step=1000.0 * boundary / args.boundary_steps,
                                    host_bytes_in_per_pair=round(float(rs.lens.sum()) / rs.n_pairs + 8, 1), host_bytes_out_per_pair=round(out_bytes / rs.n_pairs, 1),

@@ -23,7 +23,7 @@ def _free_port():
 
 def _bench(tmp, n):
     args = ["bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--lib", SIM, "--backend", "gloo", "--genome-len", "300000",
-            "--barcodes", "3", "--pairs-per-barcode", "40", "--chunk-pairs", "80", "--cache", str(tmp), "--no-cpu-baseline"]
+            "--barcodes", "3", "--pairs-per-barcode", "40", "--chunk-pairs", "80", "--cache", str(tmp), "--no-cpu-baseline", "--scatter-steps", "1"]
     if n == 1:
         cmd = [sys.executable] + args
     else:
@@ -48,3 +48,6 @@ def test_two_ranks_shard_by_barcode_groups(built, tmp_path):
     assert abs(two["value"] * two["ms_per_step"] / 1000.0 - 240) < 1e-6                # value = pairs of ALL ranks / max-over-ranks time
     for k in ("metric", "unit", "steps", "warmup", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert k in two
+    # the scatter / gather dataflow ran as well: rank 0 assigned whole barcodes of both ranks' read sets (6 barcodes x 40 pairs) by pair count
+    assert sorted(two["scatter_gather"]["pairs_per_rank"]) == [120, 120] and "scatter_gather" not in one
+    assert two["boundary"]["value"] > 0
