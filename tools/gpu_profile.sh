@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --no-cpu-baseline"   # the default command (K = 10 timed steps after 2 warm-up steps) minus the CPU leg
+ARGS="bench.py --no-cpu-baseline --boundary-steps 0 ${ARX_PROFILE_ARGS:-}"   # the default command (GRCh38-size workload, K = 10 timed steps after 2 warm-up steps) minus the CPU leg and the boundary pass
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err   # also warms the index cache in /tmp
 echo "plain rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err

@@ -55,6 +55,25 @@ for nm in ("bench_plain", "bench_trace"):
         res[nm] = json.loads(open(os.path.join(out, nm + ".json")).read().strip().splitlines()[-1])
     except Exception as e:
         res[nm] = repr(e)
+# memory-side bytes per read of the seeding kernels (bench.py's roofline.traffic reads this file from profiles/r02/)
+try:
+    bp = res.get("bench_plain", {})
+    cal = (res.get("fetch_calibration") or {}).get("bytes_per_raw_byte") or 1.0
+    reads_per_launch = bp["roofline"]["reads_per_launch"]
+    def per_read(names, launches_per_batch):
+        raw = sum(pmc[k]["FETCH_SIZE"] for k in names if k in pmc and "FETCH_SIZE" in pmc[k])
+        disp = max(pmc[k]["dispatches_pmc_fetch"] for k in names if k in pmc)
+        return raw * 1024.0 * cal / (disp / launches_per_batch) / reads_per_launch
+    traffic = dict(source="rocprofv3 --pmc FETCH_SIZE over `python3 " + "bench.py --no-cpu-baseline --boundary-steps 0" + "` (its own pass, tools/gpu_profile.sh); FETCH_SIZE x 1024 x calibration factor, per seeding-stage run of %d reads" % reads_per_launch,
+                   calibration=res.get("fetch_calibration"), workload=bp["config"]["workload"],
+                   bwd_fabric_bytes_per_read=per_read(["k_seed_bwd", "k_seed_bwd_wave"], 2.0), fwd_fabric_bytes_per_read=per_read(["k_seed_fwd1", "k_seed_fwd2"], 1.0),
+                   strat_fabric_bytes_per_read=per_read(["k_strat_dyn"], 1.0), locate_fabric_bytes_per_read=per_read(["k_locate_dyn"], 1.0),
+                   algorithmic=dict(bwd=bp["roofline"]["algorithmic_bytes_per_read"], fwd=bp["roofline_fwd"]["algorithmic_bytes_per_read"],
+                                    strat=bp["roofline_strat"]["algorithmic_bytes_per_read"], locate=bp["roofline_locate"]["algorithmic_bytes_per_read"]))
+    json.dump(traffic, open(os.path.join(out, "seed_traffic.json"), "w"), indent=1)
+    print("seed traffic per read:", {k: round(v) for k, v in traffic.items() if k.endswith("per_read")}, "algorithmic:", traffic["algorithmic"])
+except Exception as e:
+    print("seed traffic not derived:", repr(e))
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 ks = {r["kernel"]: r for r in res.get("kernel_stats", [])}
 print("kernel trace (avg ms per launch):", {k: round(v["avg_ms"], 3) for k, v in list(ks.items())[:12]})
