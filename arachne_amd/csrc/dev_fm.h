@@ -51,11 +51,11 @@ ARX_DEVI uint64_t head_cum(const OccHead &h, int c) // compile-time c in the cal
 }
 ARX_DEVI uint32_t head_ck(const OccHead &h, int q) { return q == 0 ? 0u : q == 1 ? h.hx.y : q == 2 ? h.hx.z : h.hx.w; }
 
-// counts of the four symbols among the first n (1..128) symbols of the block, added to the cumulative counts
-ARX_DEVI void block_occ4(const uint32_t *blk, const OccHead &h, int n, uint64_t cnt[4])
+// counts of the four symbols among the first n (1..128) symbols of the block, added to the cumulative counts; w = the quarter word
+// holding symbol n - 1 (load_quarter(blk, (n - 1) >> 5))
+ARX_DEVI void block_occ4_w(const OccHead &h, uint64_t w, int n, uint64_t cnt[4])
 {
 	const int q = (n - 1) >> 5, nj = n - 32 * q; // nj in 1..32
-	const uint64_t w = load_quarter(blk, q);
 	const uint64_t keep = ~0ull << (64 - 2 * nj);
 	const uint64_t lo = w & 0x5555555555555555ull & keep, hi = (w >> 1) & 0x5555555555555555ull & keep;
 	const uint32_t p3 = (uint32_t)__builtin_popcountll(hi & lo);
@@ -67,6 +67,7 @@ ARX_DEVI void block_occ4(const uint32_t *blk, const OccHead &h, int n, uint64_t 
 	cnt[2] = head_cum(h, 2) + ((ck >> 16) & 0xff) + c2;
 	cnt[3] = head_cum(h, 3) + (ck >> 24) + p3;
 }
+ARX_DEVI void block_occ4(const uint32_t *blk, const OccHead &h, int n, uint64_t cnt[4]) { block_occ4_w(h, load_quarter(blk, (n - 1) >> 5), n, cnt); }
 
 // bwt_occ4 (bwt.c:169-187): counts in B[0..k] of the $-removed BWT.  Touches exactly one 64-byte block.
 ARX_DEVI void occ4(const IndexView &ix, uint64_t k, uint64_t cnt[4])
@@ -128,6 +129,45 @@ ARX_DEVI Biv extend1(const IndexView &ix, const Biv &ik, int is_back, int c)
 	return ok;
 }
 
+// extend1() cut in two, for kernels that want every load of an iteration in flight before anything waits (hip_fm_coop.h
+// k_seed_bwd2): ext_issue() computes the two rows and loads their blocks (head + the one quarter each row needs), ext_finish() is
+// the arithmetic.  Same values as extend1().
+struct ExtLoad { OccHead hk, hl; uint64_t wk, wl; int nk, nl; }; // nk / nl: symbols counted in the block (0: the row is -1, counts are zero)
+// `on` = the lane has a request; lanes without one (and rows that are -1) load block 0 and count nothing: the loads are issued by every
+// lane without a branch around them, so the compiler has no reason to wait for one before issuing the next
+ARX_DEVI void ext_issue(const IndexView &ix, const Biv &ik, int is_back, bool on, ExtLoad &L)
+{
+	const uint64_t a = is_back ? ik.k : ik.l;
+	uint64_t k = a - 1, l = a - 1 + ik.s;
+	const bool vk = on && k != (uint64_t)-1, vl = on && l != (uint64_t)-1;
+	k -= (k >= ix.primary); l -= (l >= ix.primary);
+	const uint32_t *bk = ix.bwt + (vk ? (k >> 7) << 4 : 0), *bl = ix.bwt + (vl ? (l >> 7) << 4 : 0);
+	L.nk = vk ? (int)(k & 127) + 1 : 0;
+	L.nl = vl ? (int)(l & 127) + 1 : 0;
+	L.hk = load_head(bk); L.wk = load_quarter(bk, L.nk ? (L.nk - 1) >> 5 : 0);
+	L.hl = load_head(bl); L.wl = load_quarter(bl, L.nl ? (L.nl - 1) >> 5 : 0);
+}
+ARX_DEVI Biv ext_finish(const IndexView &ix, const Biv &ik, int is_back, int c, const ExtLoad &L)
+{
+	const uint64_t a = is_back ? ik.k : ik.l, b = is_back ? ik.l : ik.k;
+	uint64_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0};
+	if (L.nk) block_occ4_w(L.hk, L.wk, L.nk, tk);
+	if (L.nl) block_occ4_w(L.hl, L.wl, L.nl, tl);
+	const uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1];
+	uint64_t x = b + (a <= ix.primary && a + ik.s - 1 >= ix.primary);
+	if (c < 3) x += s3;
+	if (c < 2) x += s2;
+	if (c < 1) x += s1;
+	Biv ok;
+	const uint64_t tkc = sel4(tk, c), tlc = sel4(tl, c);
+	const uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+	const uint64_t na = l2c + 1 + tkc;
+	ok.s = tlc - tkc;
+	if (is_back) { ok.k = na; ok.l = x; } else { ok.l = na; ok.k = x; }
+	ok.info = 0;
+	return ok;
+}
+
 ARX_DEVI Biv set_intv(const IndexView &ix, int c) // bwt_set_intv (bwt.h:78)
 {
 	Biv ik;
@@ -173,6 +213,9 @@ ARX_DEVI uint64_t sa_lookup(const IndexView &ix, uint64_t k)
 // second list of the sweep, [2n, 3n) the SMEMs it finds.
 struct QBytes { const uint8_t *p; ARX_DEVI int at(int i) const { return p[i]; } };       // base codes 0..4, one per byte
 struct QNibbles { const uint8_t *p; ARX_DEVI int at(int i) const { return (p[i >> 1] >> ((i & 1) << 2)) & 15; } }; // two per byte (LDS staging)
+// the same rows laid out word-major across the 64 lanes of a wavefront (word w of lane x at byte 256 w + 4 x: what a lane-linear
+// LDS-direct load writes); p points at the lane's word 0
+struct QNibblesT { const uint8_t *p; ARX_DEVI int at(int i) const { return (p[((i >> 3) << 8) + ((i >> 1) & 3)] >> ((i & 1) << 2)) & 15; } };
 
 struct SeedTask { // off/n: pool slice; nm: SMEMs found; next: the read's next task (-1: last)
 	int32_t read, x, min_intv, off, n, nm, next;
@@ -260,9 +303,21 @@ template <class Q> struct BwdLane {
 		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
 		prev0 = prev[0]; curr0 = Biv();
 	}
+	// the list entry the lane will ask for after the one it is extending now, or `dummy` when there is none (end of the row: the next
+	// row starts from curr0, a register)
+	ARX_DEVI bool has_next_entry() const { return !finished && in_row && j + 1 < n_prev; }
+	ARX_DEVI void start_with(const Q &q_, const SeedTask &t, Biv *pool, const Biv &first) // start() with prev[0] already in hand
+	{
+		n_done = 0; handed = 0;
+		q = q_; prev = pool + t.off; curr = prev + t.n; mem = curr + t.n; min_intv = t.min_intv;
+		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
+		prev0 = first; curr0 = Biv();
+	}
 	// budget > 0: after that many extensions the sweep stops at the next row boundary (handed = 1): a sweep over a repeat
 	// can be ten times longer than the typical one, and a lane that is alone with it keeps its whole wavefront waiting
-	ARX_DEVI bool advance(Biv *req, int *rc, int budget = 0)
+	// nx (pipelined kernel): prev[j] for j >= 1, fetched by the caller while entry j - 1 was being extended (null: read it here)
+	ARX_DEVI bool advance(Biv *req, int *rc, int budget = 0) { const Biv none = Biv(); return advance_nx(req, rc, budget, false, none); }
+	ARX_DEVI bool advance_nx(Biv *req, int *rc, int budget, bool have_nx, const Biv &nx)
 	{
 		while (!finished) {
 			if (!in_row) { // backward extension by query position i (-1 = before the read)
@@ -283,7 +338,8 @@ template <class Q> struct BwdLane {
 				--i; in_row = false;
 				continue;
 			}
-			*req = j == 0 ? prev0 : prev[j]; *rc = c;
+			if (j == 0) *req = prev0; else if (have_nx) *req = nx; else *req = prev[j];
+			*rc = c;
 			return true;
 		}
 		return false;

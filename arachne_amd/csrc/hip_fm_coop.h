@@ -63,12 +63,33 @@ inline int seed_row_bytes(int max_len) { int w = ((max_len + 1) / 2 + 3) / 4; if
 #define ARX_SEED_WPE 4 // waves per SIMD the seeding kernels are compiled for (register budget 512 / WPE)
 #endif
 
+// The reads of a batch as the seeding kernels want them: 4-bit codes, two per byte (low nibble first), one fixed-stride row of `row`
+// bytes per read.  Packed once per batch (k_pack_reads); a lane that takes an item then copies ITS row into its LDS row with
+// independent dword loads -- two round trips to memory for the whole wave.  (Round 1 staged the rows cooperatively from the byte-per-base
+// array, one taken item after the other with four dependent loads each: ~40 us per refill of a wave, which forced the refills to be rare
+// -- 48 parked lanes -- and left 25-32 of 64 lanes extending on average.)
+static __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t *bases, const int32_t *base_off, const int32_t *lens, int n_reads, int row_words, uint32_t *qn)
+{
+	const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int r = (int)(g / row_words), wd = (int)(g % row_words);
+	if (r >= n_reads) return;
+	const int len = lens[r];
+	const uint8_t *b = bases + base_off[r];
+	uint32_t x = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int i = 2 * (4 * wd + k);
+		const uint32_t lo = i < len && len <= MAX_READ_LEN ? b[i] : 4, hi = i + 1 < len && len <= MAX_READ_LEN ? b[i + 1] : 4;
+		x |= (lo | hi << 4) << (8 * k);
+	}
+	qn[(size_t)r * row_words + wd] = x;
+}
+
 struct ItemFeeder {
 	int pool_next = 0, pool_end = 0; bool exhausted = false; // wave-uniform
 	// item < 0 marks an idle lane.  tasks != nullptr: items are task ids (t0 + item), the read to stage is the task's.
 	// Returns false when nothing is left and the whole wave is idle.
-	__device__ bool deal(int &item, bool &took, const SeedTask *tasks, int t0, const uint8_t *bases, const int32_t *base_off, const int32_t *lens,
-	                     int n, int32_t *counter, int chunk, uint8_t *q_lds, int row)
+	__device__ bool deal(int &item, bool &took, const SeedTask *tasks, int t0, const uint32_t *qn, int n, int32_t *counter, int chunk, uint8_t *q_lds, int row, int read0 = 0)
 	{
 		const int lane = threadIdx.x;
 		took = false;
@@ -88,19 +109,18 @@ struct ItemFeeder {
 		if (took) item = pool_next + rank;
 		const int need = __builtin_popcountll(idle);
 		pool_next += need < avail ? need : avail;
-		unsigned long long fresh = __ballot(took);
-		while (fresh) { // the wave copies the read of every newly taken item into the taking lane's LDS row, 128 bases per sweep
-			const int src = __builtin_ctzll(fresh);
-			fresh &= fresh - 1;
-			const int it = __shfl(item, src);
-			const int rs = tasks ? tasks[t0 + it].read : it;
-			const int len = lens[rs];
-			const uint8_t *b = bases + base_off[rs];
-			if (len <= MAX_READ_LEN)
-				for (int k = 2 * lane; k < len; k += 128) {
-					const int lo = b[k], hi = k + 1 < len ? b[k + 1] : 4;
-					q_lds[src * row + (k >> 1)] = (uint8_t)(lo | hi << 4);
-				}
+		if (took) { // this lane's read into this lane's LDS row (row: an odd number of words, so the lanes hit different banks)
+			const int rs = tasks ? tasks[t0 + item].read : read0 + item;
+			const int rw = row >> 2;
+			const uint32_t *src = qn + (size_t)rs * rw;
+			uint32_t *dst = (uint32_t *)(q_lds + lane * row);
+			for (int w0 = 0; w0 < rw; w0 += 8) {
+				uint32_t v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) v[u] = src[w0 + u < rw ? w0 + u : rw - 1];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) if (w0 + u < rw) dst[w0 + u] = v[u];
+			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_wave_barrier();
@@ -113,6 +133,9 @@ struct SeedKArgs { // shared by the three kernels
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int32_t *first1; int t0;
 	int32_t *heavy; int32_t *n_heavy; int budget; // backward sweeps that exceed `budget` extensions are queued here for k_seed_bwd_wave
 	int row;                                       // bytes of LDS per lane for its read (seed_row_bytes)
+	const uint32_t *qn;                            // the batch's reads as nibble rows (k_pack_reads), row / 4 words each
+	int read0;                                     // first pass: item i is read read0 + i
+	unsigned long long *dbg;                       // (diagnostics, ARX_SEED_STATS) [0] wave-iterations, [1] lane-extensions, [2] slow-path entries, [3] waves
 };
 
 // Lane programs: begin(item) after the read is staged (false: nothing to do), advance(req, rb, rc, slow_ok) -> has a request /
@@ -125,7 +148,7 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), extending(false), awaiting(false), over(true) {}
 	__device__ bool begin(int item)
 	{
-		r = item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false;
+		r = A.read0 + item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false;
 		if (len > MAX_READ_LEN) { atomicOr(A.P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len < OPT_MIN_SEED_LEN) { A.first1[r] = -1; over = true; return false; }
 		return true;
@@ -247,16 +270,14 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) { return (uint
 
 static __global__ void __launch_bounds__(64) k_seed_bwd_wave(SeedKArgs A)
 {
-	__shared__ uint8_t q_lds[SEED_ROW];
+	__shared__ __attribute__((aligned(4))) uint8_t q_lds[SEED_ROW + 4];
 	const int lane = threadIdx.x;
 	const int n_heavy = *A.n_heavy;
 	for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
 		const int t = A.heavy[h];
 		const SeedTask k = A.P.tasks[t];
-		const int len = A.lens[k.read];
-		const uint8_t *b = A.bases + A.base_off[k.read];
 		__builtin_amdgcn_wave_barrier();
-		for (int e = 2 * lane; e < len; e += 128) { const int lo = b[e], hi = e + 1 < len ? b[e + 1] : 4; q_lds[e >> 1] = (uint8_t)(lo | hi << 4); }
+		if (lane < (A.row >> 2)) ((uint32_t *)q_lds)[lane] = A.qn[(size_t)k.read * (A.row >> 2) + lane]; // the task's read: one word per lane
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -319,13 +340,16 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 	Biv req = Biv();
 	int rb = 0, rc = 0;
 	bool have_req = false;
+	unsigned long long n_it = 0, n_ext = 0, n_slow = 0;
 	for (;;) {
 		if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, false); // cheap part: the next request of a running extension
 		const int waiting = __builtin_popcountll(__ballot(!have_req));
+		if (A.dbg) { ++n_it; n_ext += 64 - waiting; }
 		if (waiting >= batch || waiting == 64) {
+			++n_slow;
 			if (item >= 0 && !have_req && prog.done()) { prog.finish(); item = -1; }
 			bool took;
-			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds, A.row)) break;
+			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.qn, n, counter, chunk, q_lds, A.row, A.read0)) break;
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
 			if (Prog::ALLOCATES) { // pool slices (and task ids) for every lane that parked for them: one atomic per cursor and wave
@@ -351,6 +375,7 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 		}
 		if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}
+	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 2, n_slow); atomicAdd(A.dbg + 3, 1ull); }
 }
 
 static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_fwd1(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
@@ -369,7 +394,95 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd(SeedKArgs 
 	persistent_lanes<BwdProg, true>(A, n, counter, batch, chunk, q_lds);
 }
 
-struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; int row; };
+// ---- the backward sweeps again, as a pipeline: ONE wait on memory per loop iteration, with everything any lane needs next in flight.
+// In k_seed_bwd a wavefront that refills its lanes stops for five dependent round trips (chunk reservation, task -> read id, read row,
+// task, first interval) while its extending lanes stand by; at GRCh38 size a round trip under load is several microseconds, a refill
+// cost ~22 us, and making refills rare (48 parked lanes) left 25-32 of 64 lanes extending (measured, profiles/r02).  Here a lane being
+// refilled walks through stages, one per iteration, its loads riding along with the Occ loads of the lanes that extend:
+//   stage 0 idle -> takes the next task id from the wave's reservation (ballot rank)          -> stage 1
+//   stage 1      -> loads its SeedTask                                                        -> stage 2
+//   stage 2      -> its read row goes to LDS by LDS-direct loads (no registers), prev[0] loads -> stage 3
+//   stage 3      running: BwdLane::advance / ext_issue | wait | ext_finish / consume
+// Sweeps that exceed the budget are flagged (no atomic in the loop); k_collect_heavy lists them for k_seed_bwd_wave.
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd2(SeedKArgs A, int n, int32_t *counter, int chunk, uint8_t *heavy_flag)
+{
+	extern __shared__ uint8_t q_lds[]; // (row / 4) words x 64 lanes, word-major
+	const int lane = threadIdx.x, rw = A.row >> 2;
+	const QNibblesT q{q_lds + lane * 4};
+	BwdLane<QNibblesT> ln;
+	ln.finished = true;
+	int stage = 0, t = -1;
+	SeedTask k = SeedTask();
+	Biv req = Biv(), nxt = Biv();
+	int rc = 0;
+	bool have_req = false;
+	int pool_next = 0, pool_end = 0; bool exhausted = false; // wave-uniform: the reserved chunk of items
+	unsigned long long n_it = 0, n_ext = 0;
+	for (;;) {
+		// A. running lanes: the next request, or the sweep is over
+		if (stage == 3 && !have_req) {
+			have_req = ln.advance_nx(&req, &rc, A.budget, true, nxt);
+			if (!have_req) {
+				SeedTask &kt = A.P.tasks[t];
+				kt.nm = ln.nm;
+				if (ln.handed) { kt.flip = ln.prev != A.P.pool + k.off; kt.row = ln.i; kt.n_prev = ln.n_prev; kt.mls = ln.mem_last_start; heavy_flag[t - A.t0] = 1; }
+				stage = 0;
+			}
+		}
+		if (A.dbg) { ++n_it; n_ext += __builtin_popcountll(__ballot(have_req)); }
+		// B. idle lanes take items
+		const unsigned long long idle = __ballot(stage == 0);
+		if (idle) {
+			if (pool_next == pool_end && !exhausted) {
+				int base = 0;
+				if (lane == 0) base = atomicAdd(counter, chunk); // a dozen reservations per wave and launch: not worth hiding
+				base = __shfl(base, 0);
+				if (base >= n) { exhausted = true; pool_next = pool_end = n; }
+				else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
+			}
+			const int avail = pool_end - pool_next;
+			if (avail > 0) {
+				const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+				if (stage == 0 && rank < avail) { t = A.t0 + pool_next + rank; stage = 1; }
+				const int need = __builtin_popcountll(idle);
+				pool_next += need < avail ? need : avail;
+			} else if (exhausted && idle == ~0ull) break;
+		}
+		// C. everything this iteration needs from memory (the scheduling barriers keep every load above every use: left alone, the
+		//    scheduler computes on the Occ blocks before it issues the other loads -- fewer registers, two round trips per iteration)
+		__builtin_amdgcn_sched_barrier(0);
+		ExtLoad L;
+		ext_issue(A.ix, req, 1, have_req, L);
+		nxt = A.P.pool[(stage == 3 && ln.has_next_entry()) ? (ln.prev - A.P.pool) + ln.j + 1 : 0]; // the sweep's next list entry rides along
+		const SeedTask kt2 = A.P.tasks[stage == 1 ? t : A.t0];   // lanes in other stages load the first task / pool entry 0 and drop it
+		const Biv p0 = A.P.pool[stage == 2 ? k.off : 0];
+		if (__ballot(stage == 2)) {
+			if (stage == 2) {
+				const uint32_t *src = A.qn + (size_t)k.read * rw;
+				for (int w = 0; w < rw; ++w)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + w), (__attribute__((address_space(3))) void *)(q_lds + w * 256), 4, 0, 0);
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// D. (the first use below waits)  E. consume
+		if (have_req) { ln.consume(req, ext_finish(A.ix, req, 1, rc, L)); have_req = false; }
+		if (stage == 2) {
+			if (k.x == 0) { // nothing lies before the read: the longest forward match is the SMEM (the sweep's c < 0 case at i = -1)
+				A.P.pool[k.off + 2 * k.n] = p0;
+				A.P.tasks[t].nm = 1;
+				stage = 0;
+			} else { ln.start_with(q, k, A.P.pool, p0); stage = 3; }
+		} else if (stage == 1) { k = kt2; stage = k.n == 0 ? 0 : 2; }
+	}
+	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 3, 1ull); }
+}
+static __global__ void __launch_bounds__(256) k_collect_heavy(const uint8_t *flag, int n, int t0, int32_t *heavy, int32_t *n_heavy)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && flag[i]) heavy[atomicAdd(n_heavy, 1)] = t0 + i;
+}
+
+struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; int row; const uint32_t *qn; };
 
 // third pass: forward extensions only, no lists -- the loop body is little more than extend1()
 static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_strat_dyn(StratArgs A, int n, int32_t *counter, int chunk)
@@ -383,7 +496,7 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_strat_dyn(StratArgs
 	for (;;) {
 		if (__ballot(r < 0)) {
 			bool took;
-			if (!feed.deal(r, took, nullptr, 0, A.bases, A.base_off, A.lens, n, counter, chunk, q_lds, A.row)) break;
+			if (!feed.deal(r, took, nullptr, 0, A.qn, n, counter, chunk, q_lds, A.row)) break;
 			if (took) {
 				const int len = A.lens[r];
 				if (len >= OPT_MIN_SEED_LEN && len <= MAX_READ_LEN) ln.start(len, QNibbles{q_lds + lane * A.row}, A.strat + (size_t)r * CAP_STRAT);

@@ -144,6 +144,19 @@ struct HipRT {
 	int max_seed_slots() const { return n_cu * seed_bpc * 64; }
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
 	void set_seed_read_len(int max_len) { seed_row = seed_row_bytes(max_len); }
+	// the batch's reads as nibble rows of seed_row bytes (hip_fm_coop.h: k_pack_reads): what the seeding kernels stage into LDS
+	const uint32_t *seed_qn = nullptr;
+	void seed_prepare(const uint8_t *bases, const int32_t *base_off, const int32_t *lens, int n_reads)
+	{
+		if (sw_simple || n_reads <= 0) return;
+		const int rw = seed_row >> 2;
+		uint32_t *q = alloc<uint32_t>((size_t)n_reads * rw + 8);
+		Scope sc(*this, "seed_pack", n_reads);
+		const long long total = (long long)n_reads * rw;
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, bases, base_off, lens, n_reads, rw, q);
+		ARX_HIP_CHECK(hipGetLastError());
+		seed_qn = q;
+	}
 
 	// Kernel timing: a pair of HIP events around each launch on the launch stream, recorded without blocking and
 	// resolved (hipEventElapsedTime) the next time the stream is known to be idle.
@@ -264,7 +277,28 @@ struct HipRT {
 	int seed_bwd_budget = getenv("ARX_SEED_BWD_BUDGET") ? atoi(getenv("ARX_SEED_BWD_BUDGET")) : 128; // extensions a lane spends on one backward sweep before handing it to a wavefront (0: never)
 	int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64; // items a wavefront reserves per atomic
 	int seed_bwd_chunk = getenv("ARX_SEED_BWD_CHUNK") ? atoi(getenv("ARX_SEED_BWD_CHUNK")) : (getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 32); // backward sweeps vary most in length: smaller reservations even out the end of the launch (64: 10.3 ms, 32: 9.4, 16: 9.7, 8: 10.3 per batch)
+	// 1: the pipelined backward kernel k_seed_bwd2 (one wait on memory per iteration: 51-61 of 64 lanes extending instead of 25-32, half the
+	// iterations) -- bit-identical, but no faster yet at GRCh38 size: its wave-cycles go to instruction issue (SQ_WAIT_INST_ANY 66 %) where
+	// k_seed_bwd's go to memory waits (SQ_WAIT_ANY 67 %); both end at 15 G extensions/s (profiles/r02/README.md).  Default: round 1's kernel.
+	int seed_bwd2 = getenv("ARX_SEED_BWD2") ? atoi(getenv("ARX_SEED_BWD2")) : 0;
 	int seed_bwd_batch = getenv("ARX_SEED_BWD_BATCH") ? atoi(getenv("ARX_SEED_BWD_BATCH")) : 0; // 0: seed_batch
+	// diagnostics (ARX_SEED_STATS=1): lane utilisation of the persistent-lane seeding kernels, printed per launch
+	unsigned long long *seed_dbg_buf = nullptr;
+	unsigned long long *seed_dbg()
+	{
+		if (!getenv("ARX_SEED_STATS")) return nullptr;
+		if (!seed_dbg_buf) ARX_HIP_CHECK(hipMalloc((void **)&seed_dbg_buf, 32));
+		memset0(seed_dbg_buf, 32);
+		return seed_dbg_buf;
+	}
+	void seed_dbg_report(const char *nm, int n)
+	{
+		if (!seed_dbg_buf || !getenv("ARX_SEED_STATS")) return;
+		unsigned long long h[4];
+		d2h(h, seed_dbg_buf, 32);
+		fprintf(stderr, "[arx seed stats] %s: %d items, %llu waves, %.0f iterations/wave, %.1f lanes extending per iteration, %.0f slow-path entries/wave\n", nm, n, h[3],
+		        h[3] ? (double)h[0] / h[3] : 0.0, h[0] ? (double)h[1] / h[0] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0);
+	}
 	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_, int chunk_ = 0, int batch_ = 0)
 	{
 		if (chunk_ <= 0) chunk_ = seed_chunk;
@@ -279,15 +313,17 @@ struct HipRT {
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0, nullptr, nullptr, 0, seed_row};
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0, nullptr, nullptr, 0, seed_row, seed_qn, f.read0, seed_dbg()};
 		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, seed_bpc);
+		seed_dbg_report(nm, n);
 	}
 	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *counter)
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0, nullptr, nullptr, 0, seed_row};
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, nullptr, f.t0, nullptr, nullptr, 0, seed_row, seed_qn, 0, seed_dbg()};
 		launch_seed_kernel(nm, k_seed_fwd2, n, A, counter, seed_bpc);
+		seed_dbg_report(nm, n);
 	}
 	template <class F> void run_seed_bwd(const char *nm, int n, const F &f, int32_t *counter)
 	{
@@ -296,8 +332,28 @@ struct HipRT {
 		// sweeps longer than seed_bwd_budget extensions are finished by whole wavefronts (k_seed_bwd_wave)
 		int32_t *heavy = alloc<int32_t>((size_t)n + 2);
 		memset0(heavy + n, 4);
-		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row};
+		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row, seed_qn, 0, seed_dbg()};
+		if (seed_bwd2) { // pipelined refills (k_seed_bwd2): one wait on memory per iteration
+			uint8_t *flag = alloc<uint8_t>((size_t)n + 8);
+			memset0(flag, (size_t)n);
+			memset0(counter, 4);
+			{
+				Scope sc(*this, nm, n);
+				int blocks = (n + 63) / 64; if (blocks > n_cu * seed_bpc) blocks = n_cu * seed_bpc;
+				hipLaunchKernelGGL(k_seed_bwd2, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, seed_bwd_chunk, flag);
+				ARX_HIP_CHECK(hipGetLastError());
+			}
+			seed_dbg_report(nm, n);
+			if (seed_bwd_budget > 0) {
+				Scope sc(*this, "seed_bwd_wave", n);
+				hipLaunchKernelGGL(k_collect_heavy, dim3((n + 255) / 256), dim3(256), 0, stream, flag, n, f.t0, heavy, heavy + n);
+				hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
+				ARX_HIP_CHECK(hipGetLastError());
+			}
+			return;
+		}
 		launch_seed_kernel(nm, k_seed_bwd, n, A, counter, seed_bpc, seed_bwd_chunk, seed_bwd_batch);
+		seed_dbg_report(nm, n);
 		if (seed_bwd_budget > 0) {
 			Scope sc(*this, "seed_bwd_wave", n);
 			hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
@@ -310,7 +366,7 @@ struct HipRT {
 		if (sw_simple) { launch(nm, n, f); return; }
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
-		StratArgs A{f.ix, f.bases, f.base_off, f.lens, f.strat, f.n_strat, seed_row};
+		StratArgs A{f.ix, f.bases, f.base_off, f.lens, f.strat, f.n_strat, seed_row, seed_qn};
 		int blocks = (n + 63) / 64; if (blocks > n_cu * strat_bpc) blocks = n_cu * strat_bpc;
 		hipLaunchKernelGGL(k_strat_dyn, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, seed_chunk);
 		ARX_HIP_CHECK(hipGetLastError());

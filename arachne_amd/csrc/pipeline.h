@@ -32,8 +32,10 @@ ARX_DEVI void raise_err(uint32_t *e, uint32_t bit) { ARX_ATOMIC_OR(e, bit); } //
 // HIP runtime drives the same lane programs with persistent lanes instead (hip_fm_coop.h).
 struct KSeedFwd1 { // first pass, forward halves: the starts of a read chain through bwt_smem1a's return value
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; Biv *scratch; int list_cap; int32_t *first1;
-	ARX_DEV void operator()(int r, int slot) const
+	int read0; // the group of reads this launch covers starts here (stage_seed)
+	ARX_DEV void operator()(int item, int slot) const
 	{
+		const int r = read0 + item;
 		int len = lens[r], head = -1, last = -1;
 		if (len > MAX_READ_LEN) { raise_err(P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len >= OPT_MIN_SEED_LEN) {
@@ -76,9 +78,10 @@ struct KSeedBwd { // the backward sweep of task t0 + item
 };
 
 struct KSeedGather1 {
-	const uint8_t *bases; const int32_t *base_off; SeedPools P; const int32_t *first1; Biv *intv; int32_t *n_intv, *first2;
-	ARX_DEV void operator()(int r, int) const
+	const uint8_t *bases; const int32_t *base_off; SeedPools P; const int32_t *first1; Biv *intv; int32_t *n_intv, *first2; int read0;
+	ARX_DEV void operator()(int item, int) const
 	{
+		const int r = read0 + item;
 		int ovf = 0, f2 = -1;
 		n_intv[r] = seed_gather_pass1(P, r, first1[r], bases + base_off[r], intv + (size_t)r * CAP_INTV, CAP_INTV, &ovf, &f2);
 		first2[r] = f2;
@@ -103,9 +106,10 @@ struct KSeedFwd2 { // forward half of re-seeding task t0 + item; its pool slice 
 };
 
 struct KSeedGather2 {
-	SeedPools P; const int32_t *first2; Biv *intv; int32_t *n_intv;
-	ARX_DEV void operator()(int r, int) const
+	SeedPools P; const int32_t *first2; Biv *intv; int32_t *n_intv; int read0;
+	ARX_DEV void operator()(int item, int) const
 	{
+		const int r = read0 + item;
 		int ovf = 0;
 		n_intv[r] = seed_gather_pass2(P, first2[r], intv + (size_t)r * CAP_INTV, n_intv[r], CAP_INTV, &ovf);
 		if (ovf) raise_err(P.err, ERR_INTV_OVERFLOW);
@@ -403,6 +407,7 @@ public:
 	RT &rt;
 	IndexView ix;
 	bool trace = getenv("ARX_TRACE") != nullptr; // per-round progress on stderr
+	int seed_group_reads = getenv("ARX_SEED_GROUP") ? atoi(getenv("ARX_SEED_GROUP")) : 0; // reads per pass through the first two seeding passes (0: the whole batch at once; groups shrink the interval pool from 12 KB to 12 KB x group / batch per read at the price of under-filled forward launches: 0 / 360 k / 180 k / 90 k reads -> 7.0 / 9.5 / 11.4 / 14.1 ms of seed_fwd per 667 k-read batch, seed_bwd unchanged)
 	int seed_pool_per_read = getenv("ARX_SEED_POOL") ? atoi(getenv("ARX_SEED_POOL")) : 384; // interval-pool entries per read (3 per forward-list entry); an overflow is reported, never silent
 	explicit Pipeline(RT &rt_, const IndexView &ix_) : rt(rt_), ix(ix_) {}
 
@@ -471,6 +476,7 @@ public:
 	{
 		const int R = b.n_reads, slots = rt.max_seed_slots() > rt.max_slots() ? rt.max_seed_slots() : rt.max_slots(), list_cap = b.max_len + 2;
 		rt.set_seed_read_len(b.max_len);
+		rt.seed_prepare(b.bases, b.base_off, b.lens, R);
 		w.err = rt.template alloc<uint32_t>(4); rt.memset0(w.err, 16);
 		w.counter = rt.template alloc<int32_t>(4);
 		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);
@@ -478,30 +484,39 @@ public:
 		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
 		Biv *strat = rt.template alloc<Biv>((size_t)R * CAP_STRAT);
 		int32_t *n_strat = rt.template alloc<int32_t>(R + 1);
-		// first two passes: forward chains -> backward tasks -> gather + re-seeding tasks -> their forward and backward halves -> gather
+		// first two passes: forward chains -> backward tasks -> gather + re-seeding tasks -> their forward and backward halves -> gather,
+		// optionally one GROUP of reads after the other through the same (group-sized) interval pool and task array (ARX_SEED_GROUP).
+		// Tried in round 2 because scattered 64-byte reads run at 52 G blocks/s while a kernel's footprint stays within ~3.5 GiB and at
+		// 28-34 G/s beyond (tools/calib_random.hip: the reach of the address translation caches) and the GRCh38 Occ table alone is 2.9 GiB;
+		// measured: the pool's footprint is NOT what holds the backward sweeps back (no change), so the default is one group.
+		const int GR = seed_group_reads > 0 ? seed_group_reads : R;
+		const int Rg_max = GR < R ? GR : R;
 		SeedPools P;
-		P.pool_cap = (int64_t)R * seed_pool_per_read; P.task_cap = (int32_t)((int64_t)R * 12 < 0x7fffffff ? R * 12 : 0x7fffffff);
+		P.pool_cap = (int64_t)Rg_max * seed_pool_per_read; P.task_cap = (int32_t)((int64_t)Rg_max * 12 < 0x7fffffff ? Rg_max * 12 : 0x7fffffff);
 		P.pool = rt.template alloc<Biv>((size_t)P.pool_cap + 1); P.tasks = rt.template alloc<SeedTask>((size_t)P.task_cap + 1);
 		P.cursors = rt.template alloc<int32_t>(2); P.err = w.err;
-		rt.memset0(P.cursors, 8);
 		int32_t *first1 = rt.template alloc<int32_t>(R + 1), *first2 = rt.template alloc<int32_t>(R + 1);
-		int32_t cur[2];
-		KSeedFwd1 kf{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, first1};
-		rt.run_seed_fwd1("seed_fwd", R, kf, w.counter);
-		rt.d2h(cur, P.cursors, 8);
-		const int n1 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
-		KSeedBwd kb{ix, b.bases, b.base_off, b.lens, P, 0};
-		rt.run_seed_bwd("seed_bwd", n1, kb, w.counter);
-		KSeedGather1 kg1{b.bases, b.base_off, P, first1, w.intv, w.n_intv, first2};
-		rt.launch_wide("seed_gather", R, kg1);
-		rt.d2h(cur, P.cursors, 8);
-		const int n2 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
-		KSeedFwd2 kf2{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, n1};
-		rt.run_seed_fwd2("seed_fwd", n2 - n1, kf2, w.counter);
-		kb.t0 = n1;
-		rt.run_seed_bwd("seed_bwd", n2 - n1, kb, w.counter);
-		KSeedGather2 kg2{P, first2, w.intv, w.n_intv};
-		rt.launch_wide("seed_gather", R, kg2);
+		for (int g0 = 0; g0 < R; g0 += GR) {
+			const int Rg = R - g0 < GR ? R - g0 : GR;
+			int32_t cur[2];
+			rt.memset0(P.cursors, 8);
+			KSeedFwd1 kf{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, first1, g0};
+			rt.run_seed_fwd1("seed_fwd", Rg, kf, w.counter);
+			rt.d2h(cur, P.cursors, 8);
+			const int n1 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
+			KSeedBwd kb{ix, b.bases, b.base_off, b.lens, P, 0};
+			rt.run_seed_bwd("seed_bwd", n1, kb, w.counter);
+			KSeedGather1 kg1{b.bases, b.base_off, P, first1, w.intv, w.n_intv, first2, g0};
+			rt.launch_wide("seed_gather", Rg, kg1);
+			rt.d2h(cur, P.cursors, 8);
+			const int n2 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
+			KSeedFwd2 kf2{ix, b.bases, b.base_off, b.lens, P, w.smem_scr, list_cap, n1};
+			rt.run_seed_fwd2("seed_fwd", n2 - n1, kf2, w.counter);
+			kb.t0 = n1;
+			rt.run_seed_bwd("seed_bwd", n2 - n1, kb, w.counter);
+			KSeedGather2 kg2{P, first2, w.intv, w.n_intv, g0};
+			rt.launch_wide("seed_gather", Rg, kg2);
+		}
 		KSeedStrat k3{ix, b.bases, b.base_off, b.lens, strat, n_strat};
 		rt.run_seed_strat("seed_strat", R, k3, w.counter);
 		KSeedMerge km{w.intv, w.n_intv, strat, n_strat, w.n_occ, w.err};

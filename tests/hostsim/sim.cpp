@@ -109,6 +109,7 @@ struct SimRT {
 	// poison fresh memory: hipMalloc does not zero either, so nothing may rely on it
 	template <class T> T *alloc(size_t n) { size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); memset(p, 0xAB, b); return (T *)p; }
 	void free(void *p) { ::free(p); }
+	void seed_prepare(const uint8_t *, const int32_t *, const int32_t *, int) {}
 	std::vector<uint8_t> stage_mem;
 	void *stage(size_t bytes) { stage_mem.assign(bytes + 8, 0xCD); return stage_mem.data(); }
 	void h2d_staged(void *d, const void *s, size_t bytes) { memcpy(d, s, bytes); }

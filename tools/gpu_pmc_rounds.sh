@@ -3,9 +3,9 @@
 export TMPDIR=/tmp ROUNDS_BRIEF=1
 OUT=$PWD/gpurun_out/pmc_rounds
 rm -rf $OUT; mkdir -p $OUT
-python3 tools/gpu_rounds.py 350 > $OUT/plain.txt 2>&1   # warms the index cache
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -- python3 tools/gpu_rounds.py 350 > $OUT/sq.txt 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_FLAT --output-format csv -d $OUT/sq2 -- python3 tools/gpu_rounds.py 350 > $OUT/sq2.txt 2>&1
+python3 tools/gpu_rounds.py 4333 grch38 > $OUT/plain.txt 2>&1   # warms the index cache
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -- python3 tools/gpu_rounds.py 4333 grch38 > $OUT/sq.txt 2>&1
+rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_FLAT --output-format csv -d $OUT/sq2 -- python3 tools/gpu_rounds.py 4333 grch38 > $OUT/sq2.txt 2>&1
 python3 - <<'PY'
 import csv, glob, collections, re, os
 out = os.environ.get("OUT", "gpurun_out/pmc_rounds")
