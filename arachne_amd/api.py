@@ -83,6 +83,11 @@ def _load(path):
     lib.arx_feeder_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp), C.c_char_p, i32]
     lib.arx_feeder_next.argtypes = [vp, i64, vp]
     lib.arx_feeder_close.argtypes = [vp]
+    lib.arx_bam_open.argtypes = [C.c_char_p, i32, vp, vp, C.c_char_p, i32, i32, C.POINTER(vp), C.c_char_p, i32]
+    lib.arx_bam_write.argtypes = [vp, vp]
+    lib.arx_bam_close.argtypes = [vp, vp]
+    lib.arx_bam_error.restype = C.c_char_p
+    lib.arx_bam_error.argtypes = [vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     return lib
@@ -278,6 +283,56 @@ class Feeder:
             self.close()
         except Exception:
             pass
+
+
+class _BamBatch(C.Structure):
+    _fields_ = [("n_records", C.c_int64), ("name_off", C.c_void_p), ("names", C.c_void_p), ("flag", C.c_void_p), ("rid", C.c_void_p), ("pos", C.c_void_p),
+                ("mapq", C.c_void_p), ("mate_rid", C.c_void_p), ("mate_pos", C.c_void_p), ("tlen", C.c_void_p), ("cigar_off", C.c_void_p), ("cigars", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq", C.c_void_p), ("qual", C.c_void_p), ("qual_offset", C.c_int32), ("aux_off", C.c_void_p), ("aux", C.c_void_p)]
+
+
+class BamWriter:
+    """The BAM sink behind the path (arx_bam_*): records in batches of flat arrays, encoded and BGZF-compressed on `threads` host threads.
+    Host code of the product library; needs no GPU."""
+
+    def __init__(self, path: str, contig_names, contig_lens, extra_header: str = "", threads: int = 8, level: int = -1, lib_path: str = LIB_PATH):
+        self.lib = _load(lib_path)
+        self.h = C.c_void_p()
+        n = len(contig_names)
+        names = (C.c_char_p * n)(*[x.encode() for x in contig_names])
+        lens = np.ascontiguousarray(contig_lens, dtype=np.int32)
+        msg = C.create_string_buffer(512)
+        if self.lib.arx_bam_open(path.encode(), n, names, lens.ctypes.data, extra_header.encode() if extra_header else None, threads, level, C.byref(self.h), msg, 512) != 0:
+            raise ArachneError("arx_bam_open: " + msg.value.decode())
+
+    def write(self, names, flag, rid, pos, mapq, mate_rid, mate_pos, tlen, cigars, seqs, quals, aux, qual_offset=33):
+        """names / seqs / quals / aux: lists of bytes; cigars: list of uint32 arrays (BAM words); the rest arrays of length n."""
+        n = len(names)
+        def cat(parts, dt=np.uint8):
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(p) for p in parts])
+            flat = np.concatenate([np.frombuffer(p, dtype=np.uint8) if isinstance(p, (bytes, bytearray)) else np.asarray(p, dtype=dt) for p in parts]) if n and off[-1] else np.zeros(1, dtype=dt)
+            return off, np.ascontiguousarray(flat, dtype=dt)
+        name_off, name_b = cat(names)
+        cig_off, cig_w = cat(cigars, np.uint32)
+        seq_off, seq_b = cat(seqs)
+        _q, qual_b = cat(quals)
+        aux_off, aux_b = cat(aux)
+        keep = [np.ascontiguousarray(x, dtype=dt) for x, dt in ((flag, np.int32), (rid, np.int32), (pos, np.int32), (mapq, np.uint8), (mate_rid, np.int32), (mate_pos, np.int32), (tlen, np.int32))]
+        b = _BamBatch(n, name_off.ctypes.data, name_b.ctypes.data, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data, keep[4].ctypes.data,
+                      keep[5].ctypes.data, keep[6].ctypes.data, cig_off.ctypes.data, cig_w.ctypes.data, seq_off.ctypes.data, seq_b.ctypes.data, qual_b.ctypes.data, qual_offset,
+                      aux_off.ctypes.data, aux_b.ctypes.data)
+        if self.lib.arx_bam_write(self.h, C.byref(b)) != 0:
+            raise ArachneError("arx_bam_write: " + self.lib.arx_bam_error(self.h).decode())
+
+    def close(self):
+        st = np.zeros(4, dtype=np.int64)
+        if self.h:
+            rc = self.lib.arx_bam_close(self.h, st.ctypes.data)
+            self.h = C.c_void_p()
+            if rc != 0:
+                raise ArachneError("arx_bam_close failed")
+        return dict(records=int(st[0]), blocks=int(st[1]), bytes_in=int(st[2]), bytes_out=int(st[3]))
 
 
 def worth_running_rfa(barcode: str, n_pairs: int, unique: bool = True) -> bool:

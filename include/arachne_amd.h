@@ -148,6 +148,31 @@ int arx_feeder_open(const char *r1_path, const char *r2_path, arx_feeder **out, 
 int arx_feeder_next(arx_feeder *f, int64_t target_pairs, arx_super_batch *out);
 void arx_feeder_close(arx_feeder *f);
 
+/* ---- behind the path: the BAM sink.  The reference builds one biogo sam.Record per alignment on a single goroutine and
+ * writes it twice (BamThread / AppendBams, src/aligner/bamwriter.go:615-627,279-282), two BGZF goroutines per writer (:118).  Here records
+ * arrive in batches as flat arrays -- what AppendBam (:284-566) computes per alignment stays with the caller -- and are encoded and
+ * BGZF-compressed on `threads` host threads, blocks written in order.  One arx_bam per output file (the barcode-sorted BAM, each position
+ * bucket); host code only.  SAM/BAM specification v1 encoding; aux bytes are passed through as the caller encoded them. */
+typedef struct arx_bam arx_bam;
+typedef struct {
+	int64_t n_records;
+	const int64_t *name_off; const char *names;       /* n + 1 offsets; read names, 1..254 bytes each, no NUL */
+	const int32_t *flag, *rid, *pos;                  /* rid = -1 and pos = -1 for an unmapped record (bamwriter.go:352-356) */
+	const uint8_t *mapq;
+	const int32_t *mate_rid, *mate_pos, *tlen;
+	const int64_t *cigar_off; const uint32_t *cigars; /* BAM words: length << 4 | op, op in MIDNSHP=X = 0..8 */
+	const int64_t *seq_off; const uint8_t *seq;       /* ASCII bases as written (already reverse-complemented where the caller does, :372-375) */
+	const uint8_t *qual; int32_t qual_offset;         /* same offsets as seq; qual_offset is subtracted (33: fixQual, :240-247); 255: no qualities (0xff) */
+	const int64_t *aux_off; const uint8_t *aux;       /* BAM-encoded aux fields of each record, back to back */
+} arx_bam_batch;
+/* extra_header: further header lines (e.g. @RG, @PG), each ending in '\n', or NULL; level: zlib 0..9 (-1: 6) */
+int arx_bam_open(const char *path, int32_t n_contigs, const char *const *names, const int32_t *lens, const char *extra_header, int32_t threads, int32_t level,
+                 arx_bam **out, char *msg, int32_t msg_cap);
+int arx_bam_write(arx_bam *w, const arx_bam_batch *batch);
+/* stats[4] (may be NULL): records, BGZF blocks, uncompressed bytes, file bytes */
+int arx_bam_close(arx_bam *w, int64_t *stats);
+const char *arx_bam_error(arx_bam *w);
+
 /* intermediate results for parity tests (device -> host copies of stage outputs) */
 #define ARX_CAP_INTV 256
 int arx_batch_debug_intv(arx_ctx *ctx, arx_batch *b, int32_t *n_intv, uint64_t *intv4 /* n_reads*ARX_CAP_INTV*4 */);
