@@ -476,6 +476,151 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd2(SeedKArgs
 	}
 	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 3, 1ull); }
 }
+// ---- the backward sweeps, row-parallel: one task per 16-lane group, the entries of a row side by side in the group's lanes.
+// A sweep extends every interval of the current list by one base, keeps the survivors (dropping one that has the size of the survivor
+// before it) and repeats with the next base to the left.  k_seed_bwd gives the sweep to ONE lane: ~100 dependent extensions per task,
+// every list entry beyond the first read from and written to the batch-wide pool (measured at GRCh38 size: 0.9 32-byte stores per
+// extension, 3.6 GB of writes next to 14 GB of reads per launch, scattered partial-line writes).  Here lane j of the group holds entry
+// j in registers: a row is ONE trip to memory whatever its length, a task is as many trips as it has rows (5-10), and the lists never
+// touch memory -- the pool is read once (the forward list, <= 16 entries) and written only with the SMEMs found.  The order-dependent
+// rules of the serial loop (bwt.c:336-345: the first interval that falls below min_intv before any survivor becomes an SMEM; a survivor
+// is kept unless it has the size of the survivor before it) are ballots within the group, as in k_seed_bwd_wave; survivors move to the
+// group's low lanes through LDS.  Refills are pipelined as in k_seed_bwd2: a group that takes a task loads it in one iteration, its read
+// row and list in the next, riding along with the Occ loads of the groups that extend; one wait on memory per iteration.
+// Tasks whose forward list is longer than 16 go to k_seed_bwd_wave (64 lanes) from their first row.
+// GL = lanes per group (16, 32 or 64): tasks are binned by the length of their forward list (k_bin_tasks) and each bin runs with the
+// smallest group that holds its rows; `list` / `n_list` = the bin's task ids and their number (device memory).
+template <int GL>
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd_g(SeedKArgs A, const int32_t *list, const int32_t *n_list, int32_t *counter, int chunk, uint8_t *heavy_flag)
+{
+	constexpr int NG = 64 / GL, NW = (33 + GL - 1) / GL; // groups per wave; row words a lane copies (a row has at most 33 words)
+	const int n = *n_list;
+	extern __shared__ uint8_t lds_g16[];                      // NG read rows (A.row bytes each), then 64 exchange slots of 32 bytes
+	const int lane = threadIdx.x, g = lane / GL, gl = lane % GL, rw = A.row >> 2;
+	uint8_t *q_row = lds_g16 + g * A.row;
+	Biv *xch = (Biv *)(lds_g16 + ((NG * A.row + 31) & ~31)) + g * GL;
+	const QNibbles q{q_row};
+	const unsigned long long gmask = GL == 64 ? ~0ull : ((1ull << (GL & 63)) - 1) << (GL * g);
+	int stage = 0, t = -1;                                    // group-uniform: 0 idle, 1 task id taken, 2 task loaded, 3 running
+	SeedTask k = SeedTask();
+	Biv ent = Biv();                                          // this lane's entry of the current row (valid: gl < n_prev)
+	int i = 0, n_prev = 0, nm = 0, mls = 0, c = 0;            // group-uniform sweep state
+	int pool_next = 0, pool_end = 0; bool exhausted = false;  // wave-uniform
+	unsigned long long n_it = 0, n_ext = 0;
+	for (;;) {
+		// A. running groups: the base to extend by, or the sweep is over
+		bool ext = false;
+		if (stage == 3) {
+			bool over = i < -1;
+			if (!over) {
+				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
+				if (c < 0) { // nothing can be extended: the longest interval survives if it is not contained (bwt.c:326-331)
+					if (n_prev > 0 && (nm == 0 || i + 1 < mls)) {
+						if (gl == 0) { Biv x = ent; x.info |= (uint64_t)(i + 1) << 32; A.P.pool[k.off + 2 * k.n + nm] = x; }
+						++nm; mls = i + 1;
+					}
+					over = true;
+				}
+			}
+			if (over) { if (gl == 0) A.P.tasks[t].nm = nm; stage = 0; }
+			else ext = gl < n_prev;
+		}
+		if (A.dbg) { ++n_it; n_ext += __builtin_popcountll(__ballot(ext)); }
+		// B. idle groups take tasks
+		const unsigned long long idle = __ballot(stage == 0 && gl == 0);
+		if (idle) {
+			if (pool_next == pool_end && !exhausted) {
+				int base = 0;
+				if (lane == 0) base = atomicAdd(counter, chunk);
+				base = __shfl(base, 0);
+				if (base >= n) { exhausted = true; pool_next = pool_end = n; }
+				else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
+			}
+			const int avail = pool_end - pool_next;
+			if (avail > 0) {
+				const int rank = __builtin_popcountll(idle & ((1ull << (GL * g)) - 1)); // idle groups below this one
+				if (stage == 0 && rank < avail) { t = list[pool_next + rank]; stage = 1; }
+				const int need = __builtin_popcountll(idle);
+				pool_next += need < avail ? need : avail;
+			} else if (exhausted && __ballot(stage != 0) == 0) break;
+		}
+		// C. everything this iteration needs from memory
+		__builtin_amdgcn_sched_barrier(0);
+		ExtLoad L;
+		ext_issue(A.ix, ent, 1, ext, L);
+		const SeedTask kt2 = A.P.tasks[stage == 1 ? t : A.t0];
+		const Biv e0 = A.P.pool[(stage == 2 && gl < k.n) ? k.off + gl : 0];       // the forward list, longest match first (bwt.c:322)
+		const uint32_t *src = A.qn + (size_t)(stage == 2 ? k.read : 0) * rw;
+		uint32_t wv[NW];
+#pragma unroll
+		for (int u = 0; u < NW; ++u) wv[u] = src[gl + GL * u < rw ? gl + GL * u : 0];
+		__builtin_amdgcn_sched_barrier(0);
+		// D. (the first use waits)  E. consume
+		Biv ok = Biv();
+		if (ext) ok = ext_finish(A.ix, ent, 1, c, L);
+		const bool keep = ext && ok.s >= (uint64_t)k.min_intv;
+		const unsigned long long km = (__ballot(keep) & gmask) >> (GL * g), fm = (__ballot(ext && !keep) & gmask) >> (GL * g);
+		const unsigned long long lower = (1ull << gl) - 1, below = km & lower;
+		const int p = below ? 63 - __builtin_clzll(below) : 0;
+		const uint64_t ps = shfl_u64(ok.s, GL * g + p);
+		const bool push = keep && (!below || ok.s != ps);
+		const unsigned long long pm = (__ballot(push) & gmask) >> (GL * g);
+		if (stage == 3) {
+			if (fm) { // the first interval that died, if no survivor precedes it in the row
+				const int jf = __builtin_ctzll(fm);
+				if ((km & ((1ull << jf) - 1)) == 0 && (nm == 0 || i + 1 < mls)) {
+					if (gl == jf) { Biv x = ent; x.info |= (uint64_t)(i + 1) << 32; A.P.pool[k.off + 2 * k.n + nm] = x; }
+					++nm; mls = i + 1;
+				}
+			}
+			if (push) { Biv x = ok; x.info = ent.info; xch[__builtin_popcountll(pm & lower)] = x; }
+		}
+		if (stage == 2) { // the read row of the group and its first list
+			uint32_t *dst = (uint32_t *)q_row;
+#pragma unroll
+			for (int u = 0; u < NW; ++u) if (gl + GL * u < rw) dst[gl + GL * u] = wv[u];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		if (stage == 3) {
+			const int n_curr = __builtin_popcountll(pm);
+			if (n_curr == 0) { if (gl == 0) A.P.tasks[t].nm = nm; stage = 0; }
+			else { if (gl < n_curr) ent = xch[gl]; n_prev = n_curr; --i; }
+		} else if (stage == 2) {
+			if (k.x == 0) { // nothing lies before the read: the longest forward match is the SMEM
+				if (gl == 0) { A.P.pool[k.off + 2 * k.n] = e0; A.P.tasks[t].nm = 1; }
+				stage = 0;
+			} else { ent = e0; n_prev = k.n; i = k.x - 1; nm = 0; mls = 0; stage = 3; }
+		} else if (stage == 1) {
+			k = kt2;
+			if (k.n == 0) stage = 0;
+			else if (k.n > GL) { // too long for this group size (only the 64-lane bin meets such lists): k_seed_bwd_wave walks them in chunks of 64
+				if (gl == 0) { SeedTask &kt = A.P.tasks[t]; kt.flip = 0; kt.row = k.x - 1; kt.n_prev = k.n; kt.mls = 0; heavy_flag[t - A.t0] = 1; }
+				stage = 0;
+			} else stage = 2;
+		}
+		__builtin_amdgcn_wave_barrier(); // the exchange slots are rewritten next iteration
+	}
+	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 3, 1ull); }
+}
+// task ids of [t0, t0 + n) by the group size their forward list needs: bins[0] <= 16 entries, [1] <= 32, [2] the rest; cnt[3]
+static __global__ void __launch_bounds__(256) k_bin_tasks(const SeedTask *tasks, int t0, int n, int32_t *bin0, int32_t *bin1, int32_t *bin2, int32_t *cnt)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int len = i < n ? tasks[t0 + i].n : 0; // 0: nothing to sweep (nm stays 0)
+	const int cls = len == 0 ? -1 : len <= 16 ? 0 : len <= 32 ? 1 : 2;
+	int32_t *const bins[3] = {bin0, bin1, bin2};
+#pragma unroll
+	for (int c = 0; c < 3; ++c) { // one atomic per wavefront and bin
+		const unsigned long long m = __ballot(cls == c);
+		if (!m) continue;
+		int base = 0;
+		if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(cnt + c, __builtin_popcountll(m));
+		base = __shfl(base, __builtin_ctzll(m));
+		if (cls == c) bins[c][base + __builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1))] = t0 + i;
+	}
+}
 static __global__ void __launch_bounds__(256) k_collect_heavy(const uint8_t *flag, int n, int t0, int32_t *heavy, int32_t *n_heavy)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;

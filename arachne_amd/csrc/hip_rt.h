@@ -277,10 +277,11 @@ struct HipRT {
 	int seed_bwd_budget = getenv("ARX_SEED_BWD_BUDGET") ? atoi(getenv("ARX_SEED_BWD_BUDGET")) : 128; // extensions a lane spends on one backward sweep before handing it to a wavefront (0: never)
 	int seed_chunk = getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 64; // items a wavefront reserves per atomic
 	int seed_bwd_chunk = getenv("ARX_SEED_BWD_CHUNK") ? atoi(getenv("ARX_SEED_BWD_CHUNK")) : (getenv("ARX_SEED_CHUNK") ? atoi(getenv("ARX_SEED_CHUNK")) : 32); // backward sweeps vary most in length: smaller reservations even out the end of the launch (64: 10.3 ms, 32: 9.4, 16: 9.7, 8: 10.3 per batch)
-	// 1: the pipelined backward kernel k_seed_bwd2 (one wait on memory per iteration: 51-61 of 64 lanes extending instead of 25-32, half the
-	// iterations) -- bit-identical, but no faster yet at GRCh38 size: its wave-cycles go to instruction issue (SQ_WAIT_INST_ANY 66 %) where
-	// k_seed_bwd's go to memory waits (SQ_WAIT_ANY 67 %); both end at 15 G extensions/s (profiles/r02/README.md).  Default: round 1's kernel.
-	int seed_bwd2 = getenv("ARX_SEED_BWD2") ? atoi(getenv("ARX_SEED_BWD2")) : 0;
+	// Backward sweeps: 2 (default) = row-parallel, one task per 16/32/64-lane group with the row's entries in registers (k_seed_bwd_g<GL>,
+	// tasks binned by list length): 21.5 -> 10 ms per 667 k-read batch at GRCh38 size.  1 = the pipelined one-lane-per-task kernel
+	// k_seed_bwd2 (51-61 of 64 lanes extending instead of 25-32, but no faster: profiles/r02/README.md).  0 = round 1's k_seed_bwd.
+	// All three are bit-identical.
+	int seed_bwd2 = getenv("ARX_SEED_BWD2") ? atoi(getenv("ARX_SEED_BWD2")) : 2;
 	int seed_bwd_batch = getenv("ARX_SEED_BWD_BATCH") ? atoi(getenv("ARX_SEED_BWD_BATCH")) : 0; // 0: seed_batch
 	// diagnostics (ARX_SEED_STATS=1): lane utilisation of the persistent-lane seeding kernels, printed per launch
 	unsigned long long *seed_dbg_buf = nullptr;
@@ -333,6 +334,38 @@ struct HipRT {
 		int32_t *heavy = alloc<int32_t>((size_t)n + 2);
 		memset0(heavy + n, 4);
 		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row, seed_qn, 0, seed_dbg()};
+		if (seed_bwd2 == 2 && seed_row <= 132) { // row-parallel sweeps (k_seed_bwd_g<GL>): one task per 16/32/64-lane group, lists in registers
+			uint8_t *flag = alloc<uint8_t>((size_t)n + 8);
+			int32_t *bins = alloc<int32_t>(3 * (size_t)n + 8), *cnt = alloc<int32_t>(8); // cnt[0..2]: bin sizes, cnt[4..6]: the three launches' item counters
+			memset0(flag, (size_t)n);
+			memset0(cnt, 32);
+			const int cap = n_cu * seed_bpc;
+			auto blocks_for = [&](int per_wave) { int b = (n + per_wave - 1) / per_wave; return b > cap ? cap : (b < 1 ? 1 : b); };
+			const size_t xch = 64 * 32;
+			{
+				Scope sc(*this, nm, n);
+				hipLaunchKernelGGL(k_bin_tasks, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.t0, n, bins, bins + n, bins + 2 * (size_t)n, cnt);
+				hipLaunchKernelGGL(k_seed_bwd_g<16>, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, cnt, cnt + 4, 32, flag); // one atomic per 32 tasks: 8 per atomic made the single counter the bottleneck (25 ms instead of 4.5)
+			}
+			{
+				Scope sc(*this, "seed_bwd32", n);
+				hipLaunchKernelGGL(k_seed_bwd_g<32>, dim3(blocks_for(2)), dim3(64), ((2 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins + n, cnt + 1, cnt + 5, 16, flag);
+			}
+			{
+				Scope sc(*this, "seed_bwd64", n);
+				hipLaunchKernelGGL(k_seed_bwd_g<64>, dim3(blocks_for(1)), dim3(64), (((size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins + 2 * (size_t)n, cnt + 2, cnt + 6, 2, flag); // reservations of two rounds of the wave's groups: a larger one leaves most waves idle at the end of a short bin
+				ARX_HIP_CHECK(hipGetLastError());
+			}
+			if (getenv("ARX_SEED_STATS")) { int32_t h[3]; d2h(h, cnt, 12); fprintf(stderr, "[arx seed stats] backward tasks by list length: <= 16: %d, <= 32: %d, longer: %d\n", h[0], h[1], h[2]); }
+			seed_dbg_report(nm, n);
+			{
+				Scope sc(*this, "seed_bwd_wave", n);
+				hipLaunchKernelGGL(k_collect_heavy, dim3((n + 255) / 256), dim3(256), 0, stream, flag, n, f.t0, heavy, heavy + n);
+				hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
+				ARX_HIP_CHECK(hipGetLastError());
+			}
+			return;
+		}
 		if (seed_bwd2) { // pipelined refills (k_seed_bwd2): one wait on memory per iteration
 			uint8_t *flag = alloc<uint8_t>((size_t)n + 8);
 			memset0(flag, (size_t)n);

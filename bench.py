@@ -489,11 +489,13 @@ def main():
             # The roofline kernel: the backward sweeps of bwt_smem1a, the largest of the seeding kernels (k_seed_bwd finishes its
             # longest sweeps in k_seed_bwd_wave: the pair is one launch here; each batch launches it for the first pass and for
             # the re-seeding pass, with half of the batch's backward bytes on average).
+            BWD = ["seed_bwd", "seed_bwd32", "seed_bwd64", "seed_bwd_wave"]   # one "launch" of the backward sweeps = the group kernels of the three list-length bins + the wave kernel
+
             def group(kt, names):
                 ms = sum(kt[n]["ms"] for n in names if n in kt)
                 calls = kt[names[0]]["calls"] if names[0] in kt else 0
                 return ms, calls
-            ms, calls = group(ktimes, ["seed_bwd", "seed_bwd_wave"])
+            ms, calls = group(ktimes, BWD)
             if calls:
                 launches_per_batch = 2.0
                 avg_ms = ms / calls
@@ -509,18 +511,18 @@ def main():
                     if "bwd_fabric_bytes_per_read" in tj:
                         traffic = tj["bwd_fabric_bytes_per_read"] * reads_per_launch / launches_per_batch
                         traffic_src = rel
-                out["roofline"] = dict(kernel="seed_bwd (k_seed_bwd + k_seed_bwd_wave: backward sweeps of bwt_smem1a, bwt_extend/bwt_2occ4)", bound=bound, bound_note=bound_note,
+                out["roofline"] = dict(kernel="seed_bwd (k_seed_bwd_g<16/32/64> + k_seed_bwd_wave: backward sweeps of bwt_smem1a, bwt_extend/bwt_2occ4)", bound=bound, bound_note=bound_note,
                                        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                                        traffic_unit="bytes per launch", traffic_source=traffic_src, algorithmic_bytes_per_read=ab["bwd"],
                                        reads_per_launch=reads_per_launch, launches_per_batch=launches_per_batch, avg_launch_ms=avg_ms)
-                ims, icalls = group(ktimes_iso, ["seed_bwd", "seed_bwd_wave"])
+                ims, icalls = group(ktimes_iso, BWD)
                 if icalls:
                     iso_ms = ims / icalls
                     iso = bytes_per_launch / (iso_ms * 1e-3) / 1e9
                     out["roofline"]["isolated"] = dict(achieved=iso, frac=iso / HBM_PEAK_GBS, avg_launch_ms=iso_ms,
                                                        note="same kernels, same inputs, launched alone after the timed region (in the timed region they co-run with the other batches' DP kernels)")
             # the whole seeding stage (forward extensions, backward sweeps, third pass, gathers) against its algorithmic bytes
-            stage = ["seed_fwd", "seed_bwd", "seed_bwd_wave", "seed_gather", "seed_strat", "seed_merge"]
+            stage = ["seed_pack", "seed_fwd", "seed_bwd", "seed_bwd32", "seed_bwd64", "seed_bwd_wave", "seed_gather", "seed_strat", "seed_merge"]
             for key, kt in (("roofline_seeding_stage", ktimes), ("roofline_seeding_stage_isolated", ktimes_iso)):
                 sms = sum(kt[n]["ms"] for n in stage if n in kt)
                 runs = kt["seed_strat"]["calls"] if "seed_strat" in kt else 0
