@@ -11,8 +11,11 @@ namespace arx {
 #define ARX_BLOCK_LANES 1024 // 6.4 ms (256) -> 4.3 (512) -> 3.8 (1024) per 350 k-pair batch: a barcode is one workgroup and the kernel is latency-bound
 #endif
 constexpr int BLOCK_LANES = ARX_BLOCK_LANES, SORT_LDS = 4096;
+// A barcode of TELLseq size (tens of pairs) does not need 1024 lanes and 60 KB of LDS: small barcodes run in workgroups of
+// SMALL_LANES lanes with a SMALL_SORT-entry sort buffer (15 KB: ten workgroups per CU instead of two).
+constexpr int SMALL_LANES = 256, SMALL_SORT = 1024;
 
-struct HipBlock {
+template <int BLOCK_LANES, int SORT_LDS> struct HipBlockT {
 	int tid;
 	uint64_t *l64; // BLOCK_LANES words of LDS
 	int32_t *l32;  // BLOCK_LANES + 1 words of LDS
@@ -100,14 +103,21 @@ struct HipBlock {
 	}
 };
 
-template <class F> __global__ __launch_bounds__(BLOCK_LANES) void k_block_items(F f, int n)
+using HipBlock = HipBlockT<BLOCK_LANES, SORT_LDS>;
+
+// cls / want: only the items whose class byte equals `want` (cls == nullptr: all)
+template <class F, int LANES, int SORT> __global__ __launch_bounds__(LANES) void k_block_items(F f, int n, const uint8_t *cls, int want)
 {
-	__shared__ uint64_t l64[BLOCK_LANES];
-	__shared__ int32_t l32[BLOCK_LANES + 1];
-	__shared__ uint64_t sk[SORT_LDS];
-	__shared__ int32_t sv[SORT_LDS];
-	HipBlock blk{(int)threadIdx.x, l64, l32, sk, sv};
-	for (int b = blockIdx.x; b < n; b += gridDim.x) { f(b, blk); __syncthreads(); }
+	__shared__ uint64_t l64[LANES];
+	__shared__ int32_t l32[LANES + 1];
+	__shared__ uint64_t sk[SORT];
+	__shared__ int32_t sv[SORT];
+	HipBlockT<LANES, SORT> blk{(int)threadIdx.x, l64, l32, sk, sv};
+	for (int b = blockIdx.x; b < n; b += gridDim.x) {
+		if (cls && cls[b] != want) continue; // uniform over the workgroup
+		f(b, blk);
+		__syncthreads();
+	}
 }
 
 } // namespace arx

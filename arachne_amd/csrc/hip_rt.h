@@ -227,12 +227,26 @@ struct HipRT {
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	// one work item per BLOCK_LANES-lane workgroup (hip_block.h); f(item, HipBlock&)
-	template <class F> void launch_block(const char *nm, int n, const F &f)
+	// small (host, may be null): small[i] = 1 sends item i to a SMALL_LANES-lane workgroup
+	template <class F> void launch_block(const char *nm, int n, const F &f, const uint8_t *small = nullptr)
 	{
 		if (n <= 0) return;
 		Scope sc(*this, nm, n);
-		int blocks = n < n_cu * 8 ? n : n_cu * 8;
-		hipLaunchKernelGGL(k_block_items<F>, dim3(blocks), dim3(BLOCK_LANES), 0, stream, f, n);
+		int n_small = 0;
+		if (small) for (int i = 0; i < n; ++i) n_small += small[i] ? 1 : 0;
+		if (n_small == 0) {
+			int blocks = n < n_cu * 8 ? n : n_cu * 8;
+			hipLaunchKernelGGL((k_block_items<F, BLOCK_LANES, SORT_LDS>), dim3(blocks), dim3(BLOCK_LANES), 0, stream, f, n, (const uint8_t *)nullptr, 0);
+		} else {
+			uint8_t *d = alloc<uint8_t>((size_t)n + 8);
+			h2d(d, small, (size_t)n);
+			int blocks = n_small < n_cu * 32 ? n_small : n_cu * 32;
+			hipLaunchKernelGGL((k_block_items<F, SMALL_LANES, SMALL_SORT>), dim3(blocks), dim3(SMALL_LANES), 0, stream, f, n, (const uint8_t *)d, 1);
+			if (n_small < n) {
+				blocks = n - n_small < n_cu * 8 ? n - n_small : n_cu * 8;
+				hipLaunchKernelGGL((k_block_items<F, BLOCK_LANES, SORT_LDS>), dim3(blocks), dim3(BLOCK_LANES), 0, stream, f, n, (const uint8_t *)d, 0);
+			}
+		}
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void launch_small(const char *nm, int n, const F &f)

@@ -91,7 +91,14 @@ template <class RT> struct RfaStage {
 		rt.h2d(d_bro, bro.data(), 4 * (size_t)(n_barcodes + 1)); rt.h2d(d_so, so.data(), 8 * (size_t)(n_barcodes + 1));
 		rt.h2d(d_flags, do_rfa, n_barcodes); rt.h2d(d_p10, p10.data(), 8 * p10.size());
 		KRfa kr{cand_off, d_bro, d_flags, d_so, penalty, pipe.ix.n_seqs, d_p10, cands, d_scr, d_out};
-		rt.launch_block("rfa", n_barcodes, kr);
+		// ARX_RFA_SMALL=1 (experiments): barcodes of TELLseq size in 256-lane workgroups (hip_block.h).  Measured at 4,333 barcodes x 77
+		// pairs per batch: 23.3 ms against 7.4 ms with 1,024 lanes for every barcode -- the per-barcode phases are latency chains whose
+		// length grows with the work per lane, and ten small workgroups per CU do not make up for it.  Default: off.
+		std::vector<uint8_t> small(n_barcodes, 0);
+		static const bool rfa_small = getenv("ARX_RFA_SMALL") && atoi(getenv("ARX_RFA_SMALL")) != 0;
+		if (rfa_small)
+			for (int i = 0; i < n_barcodes; ++i) small[i] = (bro[i + 1] - bro[i] <= 2 * SMALL_LANES && res.cand_off[bro[i + 1]] - res.cand_off[bro[i]] <= SMALL_SORT / 2) ? 1 : 0;
+		rt.launch_block("rfa", n_barcodes, kr, rfa_small ? small.data() : nullptr);
 		res.bc.resize(n_barcodes);
 		rt.d2h(res.bc.data(), d_out, sizeof(RfaBarcodeOut) * (size_t)n_barcodes);
 		// calculateLogMoleculePenalty (aligner.go:722-741) with libm on the host: one log10 per barcode

@@ -70,6 +70,7 @@ static int sim_rescue_check_f() { const char *e = getenv("ARX_RESCUE_CHECK"); re
 namespace arx {
 // sequential stand-in for hip_block.h's HipBlock: one "lane" runs every parallel-for in index order
 // (ARX_SIM_PFOR=1: descending, =2: a stride permutation -- a phase whose result depends on the lane order is a race on the GPU)
+constexpr int SMALL_LANES = 256, SMALL_SORT = 1024; // hip_block.h
 struct SimBlock {
 	int order = getenv("ARX_SIM_PFOR") ? atoi(getenv("ARX_SIM_PFOR")) : 0;
 	template <class F> void pfor(int n, F f)
@@ -132,7 +133,7 @@ struct SimRT {
 	template <class F> void launch(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; for (int i = 0; i < n; ++i) f(i, 0); }
 	template <class F> void launch_small(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void launch_wide(const char *nm, int n, const F &f) { launch(nm, n, f); }
-	template <class F> void launch_block(const char *nm, int n, const F &f) { tm[nm].calls++; tm[nm].items += n; SimBlock blk; for (int i = 0; i < n; ++i) f(i, blk); }
+	template <class F> void launch_block(const char *nm, int n, const F &f, const uint8_t * = nullptr) { tm[nm].calls++; tm[nm].items += n; SimBlock blk; for (int i = 0; i < n; ++i) f(i, blk); }
 	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
 	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
