@@ -107,16 +107,31 @@ ARX_HDI double rfa_mapq_value(const Cand *c, int r_lo, int r_hi, int m_lo, int m
 	}
 	const double pseudo = -10.0 - ((double)len_r - 25.0) * 0.5 + log_mol_pen;
 	rfa_top15_push(top, nt, best_single + pseudo);
+	// For a fixed candidate i the molecule term is a constant and x -> 0.5 * x + t is monotone in floating point, so the best pair
+	// score of i is the same expression on the INTEGER maximum of cand_pair_score2 over the mate's filtered candidates.  A read in a
+	// 200-copy repeat has ~190 x 190 pairs: the mate's fields (32 of a candidate's 96 bytes decide a pair) are read four candidates
+	// per round trip, their loads independent of each other.
+	for (int j = m_lo; j < m_hi; ++j) if (c[j].in_filtered && c[j].active) am = j; // the last one, as the reference's loop leaves it
 	for (int i = r_lo; i < r_hi; ++i) {
 		if (!c[i].in_filtered) continue;
 		if (c[i].active) a = i;
-		double bs = NEG;
-		for (int j = m_lo; j < m_hi; ++j) {
-			if (!c[j].in_filtered) continue;
-			if (c[j].active) am = j;
-			const double s = 0.5 * cand_pair_score2(c[i], c[j], pen2) + (c[i].active_molecule ? 0.0 : log_mol_pen);
-			if (s > bs) bs = s;
+		const int64_t ipos = c[i].pos; const int irid = c[i].rid, irev = c[i].reversed, ilap = c[i].lap2;
+		bool any = false;
+		int best2 = 0;
+		for (int j0 = m_lo; j0 < m_hi; j0 += 4) {
+			int64_t jpos[4]; int jrid[4], jrev[4], jlap[4], jflt[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const Cand &m = c[j0 + u < m_hi ? j0 + u : m_hi - 1]; jpos[u] = m.pos; jrid[u] = m.rid; jrev[u] = m.reversed; jlap[u] = m.lap2; jflt[u] = m.in_filtered; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				if (j0 + u >= m_hi || !jflt[u]) continue;
+				bool pair = false;
+				if (irev != jrev[u] && irid == jrid[u]) { const int64_t dist = irev ? ipos - jpos[u] : jpos[u] - ipos; pair = dist >= -35 && dist < 750; } // cand_is_pair
+				const int v = ilap + jlap[u] + (pair ? 0 : pen2);
+				if (!any || v > best2) { best2 = v; any = true; }
+			}
 		}
+		const double bs = any ? 0.5 * best2 + (c[i].active_molecule ? 0.0 : log_mol_pen) : NEG;
 		rfa_top15_push(top, nt, bs);
 	}
 	double total = 0.0;

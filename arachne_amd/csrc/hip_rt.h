@@ -359,15 +359,7 @@ struct HipRT {
 			{
 				Scope sc(*this, nm, n);
 				hipLaunchKernelGGL(k_bin_tasks, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.t0, n, bins, bins + n, bins + 2 * (size_t)n, cnt);
-				hipLaunchKernelGGL(k_seed_bwd_g<16>, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, cnt, cnt + 4, 32, flag); // one atomic per 32 tasks: 8 per atomic made the single counter the bottleneck (25 ms instead of 4.5)
-			}
-			{
-				Scope sc(*this, "seed_bwd32", n);
-				hipLaunchKernelGGL(k_seed_bwd_g<32>, dim3(blocks_for(2)), dim3(64), ((2 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins + n, cnt + 1, cnt + 5, 16, flag);
-			}
-			{
-				Scope sc(*this, "seed_bwd64", n);
-				hipLaunchKernelGGL(k_seed_bwd_g<64>, dim3(blocks_for(1)), dim3(64), (((size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins + 2 * (size_t)n, cnt + 2, cnt + 6, 2, flag); // reservations of two rounds of the wave's groups: a larger one leaves most waves idle at the end of a short bin
+				hipLaunchKernelGGL(k_seed_bwd_g, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, n, cnt, flag);
 				ARX_HIP_CHECK(hipGetLastError());
 			}
 			if (getenv("ARX_SEED_STATS")) { int32_t h[3]; d2h(h, cnt, 12); fprintf(stderr, "[arx seed stats] backward tasks by list length: <= 16: %d, <= 32: %d, longer: %d\n", h[0], h[1], h[2]); }
