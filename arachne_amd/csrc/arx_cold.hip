@@ -4,8 +4,83 @@
 // record and the source form that terminates); the unit is -O3 like the rest.
 #include "hip_rt.h"
 #include "pipeline.h"
+#include "dev_regs_wave.h"
 
 namespace arx {
+// One heavy pair per 64-lane workgroup: the lanes copy both region lists into LDS, the wavefront replays the rescue state machine on
+// them (w_rescue_step of dev_regs_wave.h; wave = 0: lane 0 alone runs rescue_step(), kept for A/B runs), the lanes copy the lists back.  The scratch lists of the general dedup pass (ptmp, pidx) stay in HBM.
+static __global__ void __launch_bounds__(64) k_rescue_heavy(KRescueStep f, const int32_t *list, int n, int wave)
+{
+	__shared__ Reg lds_regs[RESCUE_LDS_REGS];
+	__shared__ int new_n[2];
+	__shared__ WaveScratch ws;
+	const int lane = threadIdx.x;
+	for (int h = blockIdx.x; h < n; h += gridDim.x) {
+		const int p = list[h];
+		ResState st = f.state[p];
+		if (st.phase == 2) continue; // uniform
+		const int o0 = f.preg_off[2 * p], o1 = f.preg_off[2 * p + 1], o2 = f.preg_off[2 * p + 2];
+		const int c0 = o1 - o0, c1 = o2 - o1; // capacities (KPairCap); c0 + c1 <= RESCUE_LDS_REGS by construction of the list
+		const int n0 = f.n_regs[2 * p], n1 = f.n_regs[2 * p + 1];
+		{ // in: the live entries of both lists, word by word
+			const uint32_t *s0 = (const uint32_t *)(f.pregs + o0), *s1 = (const uint32_t *)(f.pregs + o1);
+			uint32_t *d0 = (uint32_t *)lds_regs, *d1 = (uint32_t *)(lds_regs + c0);
+			for (int k = lane; k < n0 * (int)(sizeof(Reg) / 4); k += 64) d0[k] = s0[k];
+			for (int k = lane; k < n1 * (int)(sizeof(Reg) / 4); k += 64) d1[k] = s1[k];
+		}
+		__syncthreads();
+#ifdef ARX_WAVE_STATS
+		const unsigned long long tb0 = wall_clock64();
+		if (lane == 0) { w_times.fast = w_times.general = w_times.skip = w_times.enumerate = 0; }
+		__syncthreads();
+#endif
+		if (wave) { // every lane runs the same control flow (dev_regs_wave.h)
+			Reg *rg[2] = { lds_regs, lds_regs + c0 };
+			Reg *tm[2] = { f.ptmp + o0, f.ptmp + o1 };
+			int *ix2[2] = { f.pidx + o0, f.pidx + o1 };
+			int nl[2] = { n0, n1 };
+			SwEmit em; em.tasks = f.tasks; em.n_tasks = f.n_tasks; em.n_slots = f.n_slots; em.single_slot = f.single_base + p; em.no_ahead = f.no_ahead;
+			w_rescue_step(f.ix, p, f.lens + 2 * p, rg, nl, tm, ix2, st, f.res, em, ws);
+			if (lane == 0) { f.state[p] = st; f.n_regs[2 * p] = nl[0]; f.n_regs[2 * p + 1] = nl[1]; new_n[0] = nl[0]; new_n[1] = nl[1]; }
+		} else if (lane == 0) {
+			Reg *rg[2] = { lds_regs, lds_regs + c0 };
+			Reg *tm[2] = { f.ptmp + o0, f.ptmp + o1 };
+			int *ix2[2] = { f.pidx + o0, f.pidx + o1 };
+			int *nr[2] = { f.n_regs + 2 * p, f.n_regs + 2 * p + 1 };
+			SwEmit em; em.tasks = f.tasks; em.n_tasks = f.n_tasks; em.n_slots = f.n_slots; em.single_slot = f.single_base + p; em.no_ahead = f.no_ahead;
+			rescue_step(f.ix, p, f.lens + 2 * p, rg, nr, tm, ix2, st, f.res, em);
+			f.state[p] = st;
+			new_n[0] = *nr[0]; new_n[1] = *nr[1];
+		}
+#ifdef ARX_WAVE_STATS
+		if (lane == 0) { const unsigned long long tt = wall_clock64() - tb0; const unsigned long long old = atomicMax(&g_wstat[8], tt); if (tt > old) { g_wstat[9] = w_times.fast; g_wstat[10] = w_times.general; g_wstat[11] = w_times.skip; g_wstat[12] = (unsigned long long)n0 << 32 | (unsigned)n1; }
+			atomicAdd(&g_wstat[13], tt); atomicAdd(&g_wstat[14], w_times.fast); atomicAdd(&g_wstat[15], w_times.general); atomicAdd(&g_wstat[16], w_times.skip); }
+#endif
+		__syncthreads();
+		{ // out: the lists as they are now
+			const int m0 = new_n[0], m1 = new_n[1];
+			uint32_t *t0 = (uint32_t *)(f.pregs + o0), *t1 = (uint32_t *)(f.pregs + o1);
+			const uint32_t *u0 = (const uint32_t *)lds_regs, *u1 = (const uint32_t *)(lds_regs + c0);
+			for (int k = lane; k < m0 * (int)(sizeof(Reg) / 4); k += 64) t0[k] = u0[k];
+			for (int k = lane; k < m1 * (int)(sizeof(Reg) / 4); k += 64) t1[k] = u1[k];
+		}
+		__syncthreads();
+	}
+}
+template <> void HipRT::run_rescue_heavy<KRescueStep>(const char *nm, int n, const int32_t *list, const KRescueStep &f)
+{
+	if (n <= 0) return;
+	Scope sc(*this, nm, n);
+	static const int wave = getenv("ARX_RESCUE_WAVE") ? atoi(getenv("ARX_RESCUE_WAVE")) : 1;
+	const int blocks = n < n_cu * 8 ? n : n_cu * 8;
+	hipLaunchKernelGGL(k_rescue_heavy, dim3(blocks), dim3(64), 0, stream, f, list, n, wave);
+	ARX_HIP_CHECK(hipGetLastError());
+#ifdef ARX_WAVE_STATS
+	{ unsigned long long h[24], z[24] = {0}; hipStreamSynchronize(stream); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wstat), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_wstat), z, sizeof z);
+	  fprintf(stderr, "wstat inserts %llu fast %llu gone %llu tie %llu unclean %llu noinsert-general %llu long %llu | worst block: total %llu fast %llu general %llu skip %llu (100 MHz ticks) n0 %llu n1 %llu | sums: total %llu fast %llu general %llu skip %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12] >> 32, h[12] & 0xffffffff, h[13], h[14], h[15], h[16]); }
+#endif
+}
+
 template <class F> struct ColdUsesSlots { static const bool value = true; };
 template <> struct ColdUsesSlots<KRescueStep> { static const bool value = false; }; // no per-slot scratch: may take one item per lane
 template <class F> void HipRT::launch_cold(const char *nm, int n, const F &f) { launch_cold_impl(nm, n, f, !ColdUsesSlots<F>::value); }

@@ -218,6 +218,9 @@ struct HipRT {
 	// "cold" kernels (list bookkeeping: dedup, rescue_step) are instantiated in arx_cold.hip, a translation unit of its own (-O3 like
 	// the rest since round 2; arx_dev.h ks_introsort has the story of the -O1 build they needed before)
 	template <class F> void launch_cold(const char *nm, int n, const F &f);
+	// rescue replay of the pairs with long lists, lists staged in LDS (arx_cold.hip)
+	bool rescue_heavy_ok() const { return !(getenv("ARX_RESCUE_HEAVY") && atoi(getenv("ARX_RESCUE_HEAVY")) == 0); }
+	template <class F> void run_rescue_heavy(const char *nm, int n, const int32_t *list, const F &f);
 	template <class F> void launch_cold_impl(const char *nm, int n, const F &f, bool wide = false)
 	{
 		if (n <= 0) return;

@@ -282,10 +282,22 @@ struct KPairCap {
 	}
 };
 
+// Pairs whose two region lists are long (reads in high-copy repeats: 100-190 regions each) replay their rescue loops with the lists in
+// LDS (hip_rt.h: k_rescue_heavy): the replay is one thread walking and shifting 88-byte records, a chain of dependent memory round trips
+// that costs 10-14 ms per round from HBM / L2 and a fraction of that from LDS.  heavy[p] marks such a pair (both lists with their spare
+// capacity must fit RESCUE_LDS_REGS records); the thread-per-pair kernel skips them.
+constexpr int RESCUE_HEAVY_MIN = 48, RESCUE_LDS_REGS = 680; // 680 x 88 B = 58.4 KB; with the 17 KB of the wave's sort scratch two workgroups share a CU's 160 KB
 struct KPairInit {
 	const int32_t *occ_off, *n_core, *preg_off; const Reg *regs; Reg *pregs; int32_t *n_regs; ResState *state; const int32_t *core_clean;
+	const int32_t *cap; uint8_t *heavy; int32_t *heavy_list, *n_heavy; // null: no heavy path
+	int32_t heavy_min; // regions of both reads together from which a pair is heavy (RESCUE_HEAVY_MIN; ARX_RESCUE_HEAVY_MIN for tests)
 	ARX_DEV void operator()(int p, int) const
 	{
+		if (heavy) {
+			const bool hv = n_core[2 * p] + n_core[2 * p + 1] >= heavy_min && cap[2 * p] + cap[2 * p + 1] <= RESCUE_LDS_REGS;
+			heavy[p] = hv ? 1 : 0;
+			if (hv) heavy_list[ARX_ATOMIC_ADD(n_heavy, 1)] = p;
+		}
 		ResState st = ResState();
 		for (int e = 0; e < 2; ++e) {
 			const int r = 2 * p + e, n = n_core[r];
@@ -303,8 +315,10 @@ struct KRescueStep {
 	IndexView ix; const int32_t *lens, *preg_off; Reg *pregs, *ptmp; int32_t *pidx, *n_regs; ResState *state; const U8Res *res; SwTask *tasks; int32_t *n_tasks, *n_slots;
 	int32_t no_ahead;
 	int32_t single_base; // result slots [0, single_base): SWs queued ahead; single_base + pair: the pair's single SW
+	const uint8_t *heavy; // pairs the LDS kernel takes (null: none)
 	ARX_DEV void operator()(int p, int) const
 	{
+		if (heavy && heavy[p]) return;
 		ResState st = state[p];
 		if (st.phase == 2) return;
 		Reg *rg[2] = { pregs + preg_off[2 * p], pregs + preg_off[2 * p + 1] };
@@ -606,12 +620,17 @@ public:
 		rt.memset0(n_slots, 8);
 		const int q_cap = (b.max_len + 15) & ~15, t_cap = (PES_HIGH - PES_LOW + 2 * b.max_len + 31) & ~15;
 		w.sw_scr = rt.template alloc<uint8_t>((size_t)slots * (q_cap + 2 * t_cap));
-		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst, w.core_clean};
+		uint8_t *hv = nullptr; int32_t *hv_list = nullptr, *n_hv = nullptr;
+		if (rt.rescue_heavy_ok()) { hv = rt.template alloc<uint8_t>(NP + 8); hv_list = rt.template alloc<int32_t>(NP + 1); n_hv = rt.template alloc<int32_t>(2); rt.memset0(n_hv, 8); }
+		KPairInit ki{w.occ_off, w.n_core, w.preg_off, w.regs, w.pregs, w.n_regs, w.rst, w.core_clean, w.cap, hv, hv_list, n_hv, getenv("ARX_RESCUE_HEAVY_MIN") ? atoi(getenv("ARX_RESCUE_HEAVY_MIN")) : RESCUE_HEAVY_MIN};
 		rt.launch_wide("pair_init", NP, ki);
+		int n_heavy = 0;
+		if (hv) rt.d2h(&n_heavy, n_hv, 4);
 		for (int round = 0;; ++round) {
 			rt.memset0(w.counter, 4);
-			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter, n_slots, getenv("ARX_RESCUE_NO_AHEAD") ? 1 : 0, (int32_t)(2 * w.P)};
+			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter, n_slots, getenv("ARX_RESCUE_NO_AHEAD") ? 1 : 0, (int32_t)(2 * w.P), hv};
 			rt.launch_cold("rescue_step", NP, ks);
+			if (n_heavy > 0) rt.run_rescue_heavy("rescue_heavy", n_heavy, hv_list, ks);
 			int nt = read_counter(w);
 			if (trace) { fprintf(stderr, "[arx] rescue round %d: %d tasks\n", round, nt); fflush(stderr); }
 			if (nt == 0) {

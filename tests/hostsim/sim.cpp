@@ -111,6 +111,8 @@ struct SimRT {
 	template <class T> T *alloc(size_t n) { size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); memset(p, 0xAB, b); return (T *)p; }
 	void free(void *p) { ::free(p); }
 	void seed_prepare(const uint8_t *, const int32_t *, const int32_t *, int) {}
+	bool rescue_heavy_ok() const { return getenv("ARX_SIM_RESCUE_HEAVY") != nullptr; } // the host double can run the split (same serial code on the flagged pairs)
+	template <class F> void run_rescue_heavy(const char *nm, int n, const int32_t *list, const F &f) { F g = f; g.heavy = nullptr; tm[nm].calls++; for (int i = 0; i < n; ++i) g(list[i], 0); }
 	std::vector<uint8_t> stage_mem;
 	void *stage(size_t bytes) { stage_mem.assign(bytes + 8, 0xCD); return stage_mem.data(); }
 	void h2d_staged(void *d, const void *s, size_t bytes) { memcpy(d, s, bytes); }

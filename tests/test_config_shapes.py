@@ -87,6 +87,19 @@ def test_segdup_reads_gpu(built):
     assert np.diff(ob["reg_off"]).max() >= 40
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("heavy_min", ["6", "48"])
+def test_long_lists_with_exact_ties_wave_rescue_gpu(built, monkeypatch, heavy_min):
+    """Pairs whose region lists are long AND full of exact ties (80 identical 3 kb copies next to a 50-copy family at 0.3 %): the rescue
+    replay of such pairs runs in the one-wavefront-per-pair kernel (dev_regs_wave.h), ties send it through its general pass.  With the
+    threshold lowered to 6 regions nearly every pair of the batch takes that kernel; 48 is the product setting."""
+    monkeypatch.setenv("ARX_RESCUE_HEAVY_MIN", heavy_min)
+    g = synth.make_genome(75, [2_000_000, 30000], repeat_families=[(80, 3000, 0.0), (50, 2000, 0.003)], n_runs=1)
+    rs = synth.make_reads(76, g, 6, 150, molecule_len=10000, molecules_per_barcode=5)
+    dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, stages=True)
+    assert np.diff(ob["reg_off"]).max() >= 40
+
+
 def _one_barcode(seed, genome_len, n_pairs):
     g = synth.make_genome(seed, [genome_len])
     rs = synth.make_reads(seed + 1, g, 1, n_pairs, molecules_per_barcode=12)
