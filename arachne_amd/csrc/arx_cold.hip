@@ -2,9 +2,16 @@
 // so that the library's units compile side by side.  Until round 2 this unit was built at -O1: hipcc 7.2 at -O2/-O3 emitted
 // a dedup kernel that never terminated on gfx950.  The cause was bisected to the optimised body of ks_introsort (arx_dev.h has the
 // record and the source form that terminates); the unit is -O3 like the rest.
+#ifdef ARX_CHAIN_STATS // diagnostics build (-DARX_CHAIN_STATS): per-phase clock of the heavy-read chaining kernel, printed per launch
+#include <hip/hip_runtime.h>
+__shared__ unsigned long long lds_cstat[8];
+__device__ unsigned long long g_cstat[24];
+#define ARX_CHAIN_T(k) do { lds_cstat[k] = wall_clock64(); } while (0)
+#endif
 #include "hip_rt.h"
 #include "pipeline.h"
 #include "dev_regs_wave.h"
+#include "dev_chain_wave.h"
 
 namespace arx {
 // One heavy pair per 64-lane workgroup: the lanes copy both region lists into LDS, the wavefront replays the rescue state machine on
@@ -78,6 +85,85 @@ template <> void HipRT::run_rescue_heavy<KRescueStep>(const char *nm, int n, con
 #ifdef ARX_WAVE_STATS
 	{ unsigned long long h[24], z[24] = {0}; hipStreamSynchronize(stream); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wstat), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_wstat), z, sizeof z);
 	  fprintf(stderr, "wstat inserts %llu fast %llu gone %llu tie %llu unclean %llu noinsert-general %llu long %llu | worst block: total %llu fast %llu general %llu skip %llu (100 MHz ticks) n0 %llu n1 %llu | sums: total %llu fast %llu general %llu skip %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12] >> 32, h[12] & 0xffffffff, h[13], h[14], h[15], h[16]); }
+#endif
+}
+
+// One read with many seed occurrences per 64-lane workgroup: the lanes copy the read's occurrences into LDS, the chaining state (lists,
+// chains, B-tree nodes, the filter's rank arrays) lives there too, the wavefront chains and filters together (dev_chain_wave.h; wave = 0:
+// lane 0 alone runs chain_and_filter(), kept for A/B runs); the kept chains and their seeds go to HBM as from KChain.
+struct ChainLds { // carved out of the dynamic LDS block for a read with n occurrences
+	Seed *occ; int32_t *rid, *next; Chain *ctmp; BtNode *nodes; int32_t *iscr, *xch; int cap_nodes;
+	static __host__ __device__ size_t bytes(int n) { return (size_t)n * (sizeof(Seed) + 4 + 4 + sizeof(Chain) + 28) + ((size_t)n / 3 + 4) * sizeof(BtNode) + 64; }
+	__device__ void carve(unsigned char *p, int n)
+	{
+		cap_nodes = n / 3 + 4;
+		occ = (Seed *)p; p += (size_t)n * sizeof(Seed);
+		ctmp = (Chain *)p; p += (size_t)n * sizeof(Chain);
+		nodes = (BtNode *)p; p += (size_t)cap_nodes * sizeof(BtNode);
+		xch = (int32_t *)p; p += 16;
+		rid = (int32_t *)p; p += (size_t)n * 4;
+		next = (int32_t *)p; p += (size_t)n * 4;
+		iscr = (int32_t *)p;
+	}
+};
+constexpr int CHAIN_LDS_SMALL = 256; // two launches: reads with up to 256 occurrences (40 KB of LDS, four workgroups per CU), and the rest (one per CU)
+static __global__ void __launch_bounds__(64) k_chain_heavy(KChain f, int n_lo, int n_hi, int32_t *cursor, int wave)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_chain[];
+	__shared__ int next_h;
+	const int lane = threadIdx.x, n_heavy = *f.n_heavy;
+	for (;;) {
+		if (lane == 0) next_h = atomicAdd(cursor, 1);
+		__syncthreads();
+		const int h = next_h;
+		__syncthreads();
+		if (h >= n_heavy) break; // every workgroup reaches this: the cursor only grows
+		const int r = f.heavy_list[h];
+		const int g0 = f.occ_off[r], n = f.occ_off[r + 1] - g0;
+		if (n < n_lo || n > n_hi) continue; // the other launch's read
+		ChainLds L; L.carve(lds_chain, n);
+		{ // in: the occurrences (16 bytes each) and their contigs
+			const uint32_t *src = (const uint32_t *)(f.occ_seed + g0);
+			uint32_t *dst = (uint32_t *)L.occ;
+			for (int k = lane; k < n * (int)(sizeof(Seed) / 4); k += 64) dst[k] = src[k];
+			for (int k = lane; k < n; k += 64) L.rid[k] = f.occ_rid[g0 + k];
+		}
+		__syncthreads();
+		int m = 0;
+		if (wave) m = w_chain_and_filter(f.ix, f.lens[r], f.intv + (size_t)r * CAP_INTV, f.n_intv[r], L.occ, L.rid, n, L.next, L.ctmp, L.nodes, L.cap_nodes, L.iscr,
+		                                 f.cout + g0, f.sout + g0, g0, L.xch);
+		else if (lane == 0) m = chain_and_filter(f.ix, f.lens[r], f.intv + (size_t)r * CAP_INTV, f.n_intv[r], L.occ, L.rid, n, L.next, L.ctmp, L.nodes, L.cap_nodes, L.iscr,
+		                                         f.cout + g0, f.sout + g0, g0);
+		if (lane == 0) {
+			if (m < 0) { raise_err(f.err, ERR_POOL_OVERFLOW); m = 0; }
+			f.n_chain[r] = m;
+#ifdef ARX_CHAIN_STATS
+			if (m > 0) {
+				const unsigned long long tt = lds_cstat[5] - lds_cstat[0];
+				for (int k = 0; k < 5; ++k) atomicAdd(&g_cstat[k], lds_cstat[k + 1] - lds_cstat[k]);
+				atomicAdd(&g_cstat[5], 1ull);
+				if (atomicMax(&g_cstat[8], tt) < tt) { for (int k = 0; k < 5; ++k) g_cstat[9 + k] = lds_cstat[k + 1] - lds_cstat[k]; g_cstat[14] = n; g_cstat[15] = m; }
+			}
+#endif
+		}
+		__syncthreads();
+	}
+}
+template <> void HipRT::run_chain_heavy<KChain>(const char *nm, int n_reads, const KChain &f)
+{
+	Scope sc(*this, nm, n_reads);
+	static const int wave = getenv("ARX_CHAIN_WAVE") ? atoi(getenv("ARX_CHAIN_WAVE")) : 1;
+	static const size_t lds_s = ChainLds::bytes(CHAIN_LDS_SMALL), lds_l = ChainLds::bytes(CHAIN_LDS_OCC);
+	static bool attr_set = false;
+	if (!attr_set) { ARX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
+	// f.n_heavy[0]: the list's length (stays on the device), [1] and [2]: the two launches' cursors into it
+	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); // the long ones first
+	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu * 4), dim3(64), lds_s, stream, f, 0, CHAIN_LDS_SMALL, f.n_heavy + 1, wave);
+	ARX_HIP_CHECK(hipGetLastError());
+#ifdef ARX_CHAIN_STATS
+	{ unsigned long long h[24], z[24] = {0}; hipStreamSynchronize(stream); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cstat), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_cstat), z, sizeof z);
+	  fprintf(stderr, "cstat reads %llu | sums (100 MHz ticks): chaining %llu traverse+weights %llu sort %llu filter %llu output %llu | worst read: total %llu = %llu %llu %llu %llu %llu, n_occ %llu kept %llu\n",
+	          h[5], h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]); }
 #endif
 }
 

@@ -5,6 +5,10 @@
 #pragma once
 #include "arx_dev.h"
 
+#ifndef ARX_CHAIN_T
+#define ARX_CHAIN_T(k) do {} while (0)   // diagnostics hook (tools: per-phase clock of the heavy-read kernel)
+#endif
+
 namespace arx {
 
 // B-tree of minimum degree t = 5: KB_DEFAULT_SIZE 512 with a 40-byte key gives t = ((512-4-8)/(8+40)+1)>>1 (kbtree.h:56,388)
@@ -166,14 +170,9 @@ ARX_DEV int chain_weight(const Chain &c, const Seed *occ, const int *next) // me
 
 struct WeightGt { const Chain *c; ARX_DEVI bool operator()(int a, int b) const { return c[a].w > c[b].w; } };
 
-// One read: occurrences [g0, g1) (already located, in interval order) -> filtered chains + their seeds, compacted.
-// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 7*(g1-g0) ints, nodes cap_nodes entries.
-// Returns the number of chains kept (mem_chain + mem_chain_flt), or -1 on pool exhaustion.
-ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int n_intv, const Seed *occ, int n_occ,
-                             int *next, Chain *ctmp, BtNode *nodes, int cap_nodes, int *iscr, Chain *cout, Seed *sout, int sout_base)
+// frac_rep: share of the query covered by seeds occurring more than max_occ times (bwamem.c:265-272)
+ARX_DEV float chain_frac_rep(int len, const Biv *intv, int n_intv)
 {
-	if (len < OPT_MIN_SEED_LEN || n_occ == 0) return 0;
-	// frac_rep: share of the query covered by seeds occurring more than max_occ times (bwamem.c:265-272)
 	int b = 0, e = 0, l_rep = 0;
 	for (int i = 0; i < n_intv; ++i) {
 		int sb = (int)(intv[i].info >> 32), se = (int)(uint32_t)intv[i].info;
@@ -182,14 +181,21 @@ ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int 
 		else e = e > se ? e : se;
 	}
 	l_rep += e - b;
-	float frac_rep = (float)l_rep / len;
-	BTree bt;
+	return (float)l_rep / len;
+}
+
+// mem_chain's loop (bwamem.c:273-307): every occurrence, in order, joins the chain the B-tree finds for it or starts a new one.
+// occ_rid[g] = bns_intv2rid of occurrence g (KOccRid: computed for all occurrences of the batch side by side -- two binary searches
+// over the contig table that this one-thread loop used to wait for, occurrence after occurrence).  Returns the number of chains, -1 on
+// pool exhaustion; bt is left ready for bt_traverse.
+ARX_DEV int chain_build(const IndexView &ix, const Seed *occ, const int32_t *occ_rid, int n_occ, int *next, Chain *ctmp, BTree &bt, BtNode *nodes, int cap_nodes, float frac_rep)
+{
 	bt.nodes = nodes; bt.ch = ctmp; bt.n_nodes = 0; bt.cap_nodes = cap_nodes; bt.n_keys = 0;
 	bt.root = bt_new(bt);
 	int n_ch = 0;
 	for (int g = 0; g < n_occ; ++g) {
 		const Seed s = occ[g];
-		int rid = intv2rid(ix, s.rbeg, s.rbeg + s.len);
+		const int rid = occ_rid[g];
 		if (rid < 0) continue; // spans contigs or the strand boundary
 		bool to_add = true;
 		if (bt.n_keys) {
@@ -205,14 +211,46 @@ ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int 
 			++n_ch;
 		}
 	}
+	return n_ch;
+}
+
+// the survivors of the filter with their seeds in list order, compacted (max_chain_extend = 1<<30 never triggers, bwamem.c:373-378)
+ARX_DEV int chain_emit(int n, const int *ord, const Chain *ctmp, const Seed *occ, const int *next, Chain *cout, Seed *sout, int sout_base)
+{
+	int m = 0, so = 0;
+	for (int i = 0; i < n; ++i) {
+		const Chain &c = ctmp[ord[i]];
+		if (c.kept == 0) continue;
+		Chain o = c;
+		o.seed_off = sout_base + so;
+		for (int g = c.head; g >= 0; g = next[g]) sout[so++] = occ[g];
+		cout[m++] = o;
+	}
+	return m;
+}
+
+// One read: occurrences [g0, g1) (already located, in interval order) -> filtered chains + their seeds, compacted.
+// Pools are per-read slices: ctmp/cout/sout/next have g1-g0 slots, iscr 7*(g1-g0) ints, nodes cap_nodes entries.
+// Returns the number of chains kept (mem_chain + mem_chain_flt), or -1 on pool exhaustion.
+ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int n_intv, const Seed *occ, const int32_t *occ_rid, int n_occ,
+                             int *next, Chain *ctmp, BtNode *nodes, int cap_nodes, int *iscr, Chain *cout, Seed *sout, int sout_base)
+{
+	if (len < OPT_MIN_SEED_LEN || n_occ == 0) return 0;
+	ARX_CHAIN_T(0);
+	BTree bt;
+	const int n_ch = chain_build(ix, occ, occ_rid, n_occ, next, ctmp, bt, nodes, cap_nodes, chain_frac_rep(len, intv, n_intv));
+	if (n_ch < 0) return -1;
+	ARX_CHAIN_T(1);
 	if (n_ch == 0) return 0;
 	int *ord = iscr, *kept_idx = iscr + n_occ; // iscr: 7 * n_occ ints
 	int *qb_ = iscr + 2 * n_occ, *qe_ = iscr + 3 * n_occ, *w_ = iscr + 4 * n_occ, *alt_ = iscr + 5 * n_occ, *first_ = iscr + 6 * n_occ; // by rank in `ord`
 	int n = bt_traverse(bt, ord); // chains in key order = the array mem_chain returns
 	// mem_chain_flt (bwamem.c:327-385)
 	for (int i = 0; i < n; ++i) { Chain &c = ctmp[ord[i]]; c.first = -1; c.kept = 0; c.w = chain_weight(c, occ, next); }
+	ARX_CHAIN_T(2);
 	WeightGt gt; gt.c = ctmp;
 	ks_introsort(n, ord, gt);
+	ARX_CHAIN_T(3);
 	// The filter compares every chain with every chain kept so far: quadratic for a read in a high-copy repeat (all its chains cover
 	// the same query span and weigh the same, so nothing is dropped early).  What a comparison looks at -- query span (chn_beg /
 	// chn_end, bwamem.c:325-326), weight, is_alt, `first` -- is laid out by rank once, and the kept chains are visited four at a
@@ -256,16 +294,9 @@ ARX_DEV int chain_and_filter(const IndexView &ix, int len, const Biv *intv, int 
 		ctmp[ord[kept_idx[i]]].first = f;
 		if (f >= 0) ctmp[ord[f]].kept = 1;
 	}
-	// max_chain_extend = 1<<30 never triggers (bwamem.c:373-378); compact the survivors with their seeds in list order
-	int m = 0, so = 0;
-	for (int i = 0; i < n; ++i) {
-		const Chain &c = ctmp[ord[i]];
-		if (c.kept == 0) continue;
-		Chain o = c;
-		o.seed_off = sout_base + so;
-		for (int g = c.head; g >= 0; g = next[g]) sout[so++] = occ[g];
-		cout[m++] = o;
-	}
+	ARX_CHAIN_T(4);
+	const int m = chain_emit(n, ord, ctmp, occ, next, cout, sout, sout_base);
+	ARX_CHAIN_T(5);
 	return m;
 }
 

@@ -221,6 +221,9 @@ struct HipRT {
 	// rescue replay of the pairs with long lists, lists staged in LDS (arx_cold.hip)
 	bool rescue_heavy_ok() const { return !(getenv("ARX_RESCUE_HEAVY") && atoi(getenv("ARX_RESCUE_HEAVY")) == 0); }
 	template <class F> void run_rescue_heavy(const char *nm, int n, const int32_t *list, const F &f);
+	// chaining of the reads with many seed occurrences, one wavefront per read on a working set in LDS (arx_cold.hip); f.heavy_list / f.n_heavy
+	bool chain_heavy_ok() const { return !(getenv("ARX_CHAIN_HEAVY") && atoi(getenv("ARX_CHAIN_HEAVY")) == 0); }
+	template <class F> void run_chain_heavy(const char *nm, int n_reads, const F &f);
 	template <class F> void launch_cold_impl(const char *nm, int n, const F &f, bool wide = false)
 	{
 		if (n <= 0) return;

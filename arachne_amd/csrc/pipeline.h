@@ -172,15 +172,27 @@ struct KLocate {
 	IndexView ix; Seed *occ_seed;
 	ARX_DEV void operator()(int g, int) const { occ_seed[g].rbeg = (int64_t)sa_lookup(ix, (uint64_t)occ_seed[g].rbeg); }
 };
+// contig of every occurrence (bns_intv2rid as mem_chain calls it, bwamem.c:281-283; < 0: spans contigs or the strand boundary)
+struct KOccRid {
+	IndexView ix; const Seed *occ_seed; int32_t *occ_rid;
+	ARX_DEV void operator()(int g, int) const { const Seed s = occ_seed[g]; occ_rid[g] = intv2rid(ix, s.rbeg, s.rbeg + s.len); }
+};
 
+// Reads with many seed occurrences (reads in high-copy repeats: 0.1 % of a GRCh38-size batch carries 65-800 of them, against a median
+// of 8) are 85 % of the thread-per-read kernel's time -- one lane walking a B-tree and chain lists in HBM, several thousand dependent
+// round trips -- while the other 99.9 % finish in a quarter of it.  KChain hands such a read to k_chain_heavy (arx_cold.hip): one
+// wavefront per read, the read's working set in LDS.
+constexpr int CHAIN_HEAVY_MIN = 64, CHAIN_LDS_OCC = 832; // 832 occurrences x 154 B of working set = 128 KB of a CU's 160 KB LDS
 struct KChain {
-	IndexView ix; const int32_t *lens; const Biv *intv; const int32_t *n_intv, *occ_off; const Seed *occ_seed;
+	IndexView ix; const int32_t *lens; const Biv *intv; const int32_t *n_intv, *occ_off; const Seed *occ_seed; const int32_t *occ_rid;
 	int32_t *next; Chain *ctmp; BtNode *nodes; int32_t *iscr; Chain *cout; Seed *sout; int32_t *n_chain; uint32_t *err;
+	int32_t *heavy_list, *n_heavy; int32_t heavy_min; // null: every read is chained by its own thread
 	ARX_DEV void operator()(int r, int) const
 	{
 		const int g0 = occ_off[r], n = occ_off[r + 1] - g0;
+		if (heavy_list && n >= heavy_min && n <= CHAIN_LDS_OCC) { heavy_list[ARX_ATOMIC_ADD(n_heavy, 1)] = r; return; }
 		const int node0 = g0 / 3 + 4 * r, node1 = occ_off[r + 1] / 3 + 4 * (r + 1);
-		int m = chain_and_filter(ix, lens[r], intv + (size_t)r * CAP_INTV, n_intv[r], occ_seed + g0, n, next + g0, ctmp + g0,
+		int m = chain_and_filter(ix, lens[r], intv + (size_t)r * CAP_INTV, n_intv[r], occ_seed + g0, occ_rid + g0, n, next + g0, ctmp + g0,
 		                         nodes + node0, node1 - node0, iscr + 7 * (size_t)g0, cout + g0, sout + g0, g0);
 		if (m < 0) { raise_err(err, ERR_POOL_OVERFLOW); m = 0; }
 		n_chain[r] = m;
@@ -463,7 +475,7 @@ public:
 
 	// everything that stays on the device between the stages of one batch
 	struct Work {
-		Biv *intv = 0, *smem_scr = 0; int32_t *n_intv = 0, *n_occ = 0, *occ_off = 0; Seed *occ_seed = 0; int32_t *core_clean = 0;
+		Biv *intv = 0, *smem_scr = 0; int32_t *n_intv = 0, *n_occ = 0, *occ_off = 0; Seed *occ_seed = 0; int32_t *occ_rid = 0, *core_clean = 0;
 		int32_t *next = 0, *iscr = 0, *n_chain = 0, *srt = 0, *idx = 0, *n_core = 0; Chain *ctmp = 0, *cout = 0; BtNode *nodes = 0; Seed *sout = 0;
 		Reg *regs = 0, *rtmp = 0; ExtState *est = 0; ExtTask *etask = 0; ExtRes *eres = 0; int32_t *counter = 0; uint32_t *err = 0;
 		int32_t *eh = 0; int32_t *cap = 0, *preg_off = 0, *n_regs = 0, *pidx = 0; Reg *pregs = 0, *ptmp = 0; ResState *rst = 0; SwTask *stask = 0; U8Res *sres = 0;
@@ -474,7 +486,7 @@ public:
 
 	void free_work(Work &w)
 	{
-		void *ptrs[] = { w.intv, w.smem_scr, w.n_intv, w.n_occ, w.occ_off, w.occ_seed, w.next, w.iscr, w.n_chain, w.srt, w.idx, w.n_core, w.ctmp, w.cout,
+		void *ptrs[] = { w.intv, w.smem_scr, w.n_intv, w.n_occ, w.occ_off, w.occ_seed, w.occ_rid, w.next, w.iscr, w.n_chain, w.srt, w.idx, w.n_core, w.ctmp, w.cout,
 		                 w.nodes, w.sout, w.regs, w.rtmp, w.est, w.etask, w.eres, w.counter, w.err, w.eh, w.cap, w.preg_off, w.n_regs, w.pidx, w.pregs,
 		                 w.ptmp, w.rst, w.stask, w.sres, w.sw_scr, w.z, w.alns, w.cig, w.nw_list };
 		for (void *p : ptrs) if (p) rt.free(p);
@@ -538,12 +550,14 @@ public:
 		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R);
 		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
 		w.T = total;
-		w.occ_seed = rt.template alloc<Seed>(w.T + 1);
+		w.occ_seed = rt.template alloc<Seed>(w.T + 1); w.occ_rid = rt.template alloc<int32_t>(w.T + 1);
 		if (w.T) {
 			KOccFill kf{w.intv, w.n_intv, w.occ_off, w.occ_seed};
 			rt.launch_wide("occ_fill", R, kf);
 			KLocate kl{ix, w.occ_seed};
 			rt.run_locate("locate", (int)w.T, kl, w.counter);
+			KOccRid kr{ix, w.occ_seed, w.occ_rid};
+			rt.launch_wide("occ_rid", (int)w.T, kr);
 		}
 		return 0;
 	}
@@ -555,8 +569,11 @@ public:
 		w.next = rt.template alloc<int32_t>(T); w.ctmp = rt.template alloc<Chain>(T); w.cout = rt.template alloc<Chain>(T);
 		w.nodes = rt.template alloc<BtNode>(T / 3 + 4 * (size_t)R + 8); w.iscr = rt.template alloc<int32_t>(7 * T + 8); w.sout = rt.template alloc<Seed>(T);
 		w.n_chain = rt.template alloc<int32_t>(R + 1);
-		KChain k{ix, b.lens, w.intv, w.n_intv, w.occ_off, w.occ_seed, w.next, w.ctmp, w.nodes, w.iscr, w.cout, w.sout, w.n_chain, w.err};
+		KChain k{ix, b.lens, w.intv, w.n_intv, w.occ_off, w.occ_seed, w.occ_rid, w.next, w.ctmp, w.nodes, w.iscr, w.cout, w.sout, w.n_chain, w.err, nullptr, nullptr,
+		         getenv("ARX_CHAIN_HEAVY_MIN") ? atoi(getenv("ARX_CHAIN_HEAVY_MIN")) : CHAIN_HEAVY_MIN};
+		if (rt.chain_heavy_ok()) { k.heavy_list = rt.template alloc<int32_t>(R + 4); k.n_heavy = k.heavy_list + R; rt.memset0(k.n_heavy, 16); }
 		rt.launch_wide("chain", R, k);
+		if (k.heavy_list) rt.run_chain_heavy("chain_heavy", R, k); // the list's length stays on the device: no host round trip
 	}
 
 	// ---- stage 4: extension rounds, then de-duplication -> core regions of every read

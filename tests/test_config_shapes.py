@@ -80,6 +80,19 @@ def test_segdup_reads_hostsim(built):
     assert np.diff(ob["reg_off"]).max() >= 25                  # the long lists are really there
 
 
+def test_heavy_item_split_hostsim(built, monkeypatch):
+    """The hand-over of heavy items (pairs with long region lists, reads with many seed occurrences) from the thread-per-item kernels to
+    their own launches, on the host double: flagging, the lists, the skip in the main kernel (the host double runs the same serial code
+    on the listed items; the wavefront versions are compared with the restatements in the GPU tests)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    monkeypatch.setenv("ARX_SIM_RESCUE_HEAVY", "1")
+    monkeypatch.setenv("ARX_SIM_CHAIN_HEAVY", "1")
+    monkeypatch.setenv("ARX_RESCUE_HEAVY_MIN", "6")
+    monkeypatch.setenv("ARX_CHAIN_HEAVY_MIN", "12")
+    g, rs = _segdup_workload(73, 900_000, 50, 3, 50)
+    _run_and_check(SIM, g, rs, stages=True)
+
+
 @pytest.mark.gpu
 def test_segdup_reads_gpu(built):
     g, rs = _segdup_workload(72, 6_000_000, 200, 8, 250)
@@ -91,9 +104,12 @@ def test_segdup_reads_gpu(built):
 @pytest.mark.parametrize("heavy_min", ["6", "48"])
 def test_long_lists_with_exact_ties_wave_rescue_gpu(built, monkeypatch, heavy_min):
     """Pairs whose region lists are long AND full of exact ties (80 identical 3 kb copies next to a 50-copy family at 0.3 %): the rescue
-    replay of such pairs runs in the one-wavefront-per-pair kernel (dev_regs_wave.h), ties send it through its general pass.  With the
-    threshold lowered to 6 regions nearly every pair of the batch takes that kernel; 48 is the product setting."""
+    replay of such pairs runs in the one-wavefront-per-pair kernel (dev_regs_wave.h), ties send it through its general pass; their
+    chaining (65+ seed occurrences per read, dozens of chains of equal weight) runs in the one-wavefront-per-read kernel
+    (dev_chain_wave.h).  With the thresholds lowered (6 regions, 4 occurrences) nearly every pair / read of the batch takes those
+    kernels; 48 / 64 are the product settings."""
     monkeypatch.setenv("ARX_RESCUE_HEAVY_MIN", heavy_min)
+    monkeypatch.setenv("ARX_CHAIN_HEAVY_MIN", "4" if heavy_min == "6" else "64")       # likewise the one-wavefront-per-read chaining kernel
     g = synth.make_genome(75, [2_000_000, 30000], repeat_families=[(80, 3000, 0.0), (50, 2000, 0.003)], n_runs=1)
     rs = synth.make_reads(76, g, 6, 150, molecule_len=10000, molecules_per_barcode=5)
     dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, stages=True)
