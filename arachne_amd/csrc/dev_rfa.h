@@ -93,7 +93,37 @@ ARX_HDI void rfa_top15_push(double *top, int &nt, double v) // keeps the 15 larg
 	top[at] = v;
 	if (nt < 15) ++nt;
 }
-ARX_HDI double rfa_mapq_value(const Cand *c, int r_lo, int r_hi, int m_lo, int m_hi, int len_r, double log_mol_pen, int penalty, int *a_out, double *largest)
+// Best pair score (half-units) of candidate i over the mate's filtered candidates [m_lo, m_hi); false: the mate has none.
+// For a fixed candidate i the molecule term is a constant and x -> 0.5 * x + t is monotone in floating point, so the best pair
+// score of i is the same expression on the INTEGER maximum of cand_pair_score2 over the mate's filtered candidates.  A read in a
+// 200-copy repeat has ~190 x 190 pairs: the mate's fields (32 of a candidate's 96 bytes decide a pair) are read four candidates
+// per round trip, their loads independent of each other.
+ARX_HDI bool rfa_pair_best2(const Cand *c, int i, int m_lo, int m_hi, int pen2, int *best2_out)
+{
+	const int64_t ipos = c[i].pos; const int irid = c[i].rid, irev = c[i].reversed, ilap = c[i].lap2;
+	bool any = false;
+	int best2 = 0;
+	for (int j0 = m_lo; j0 < m_hi; j0 += 4) {
+		int64_t jpos[4]; int jrid[4], jrev[4], jlap[4], jflt[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const Cand &m = c[j0 + u < m_hi ? j0 + u : m_hi - 1]; jpos[u] = m.pos; jrid[u] = m.rid; jrev[u] = m.reversed; jlap[u] = m.lap2; jflt[u] = m.in_filtered; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (j0 + u >= m_hi || !jflt[u]) continue;
+			bool pair = false;
+			if (irev != jrev[u] && irid == jrid[u]) { const int64_t dist = irev ? ipos - jpos[u] : jpos[u] - ipos; pair = dist >= -35 && dist < 750; } // cand_is_pair
+			const int v = ilap + jlap[u] + (pair ? 0 : pen2);
+			if (!any || v > best2) { best2 = v; any = true; }
+		}
+	}
+	*best2_out = best2;
+	return any;
+}
+constexpr int RFA_NO_PAIR = (int)0x80000000;
+// pair_best (may be null): rfa_pair_best2 of every candidate, RFA_NO_PAIR for none -- computed one candidate per lane (KMapqPair) so that
+// the read's own lane is left with the linear part
+ARX_HDI double rfa_mapq_value(const Cand *c, int r_lo, int r_hi, int m_lo, int m_hi, int len_r, double log_mol_pen, int penalty, int *a_out, double *largest,
+                              const int32_t *pair_best = nullptr)
 {
 	const double pen = (double)penalty, NEG = -1.7976931348623157e308;
 	const int pen2 = 2 * penalty;
@@ -107,30 +137,14 @@ ARX_HDI double rfa_mapq_value(const Cand *c, int r_lo, int r_hi, int m_lo, int m
 	}
 	const double pseudo = -10.0 - ((double)len_r - 25.0) * 0.5 + log_mol_pen;
 	rfa_top15_push(top, nt, best_single + pseudo);
-	// For a fixed candidate i the molecule term is a constant and x -> 0.5 * x + t is monotone in floating point, so the best pair
-	// score of i is the same expression on the INTEGER maximum of cand_pair_score2 over the mate's filtered candidates.  A read in a
-	// 200-copy repeat has ~190 x 190 pairs: the mate's fields (32 of a candidate's 96 bytes decide a pair) are read four candidates
-	// per round trip, their loads independent of each other.
 	for (int j = m_lo; j < m_hi; ++j) if (c[j].in_filtered && c[j].active) am = j; // the last one, as the reference's loop leaves it
 	for (int i = r_lo; i < r_hi; ++i) {
 		if (!c[i].in_filtered) continue;
 		if (c[i].active) a = i;
-		const int64_t ipos = c[i].pos; const int irid = c[i].rid, irev = c[i].reversed, ilap = c[i].lap2;
-		bool any = false;
 		int best2 = 0;
-		for (int j0 = m_lo; j0 < m_hi; j0 += 4) {
-			int64_t jpos[4]; int jrid[4], jrev[4], jlap[4], jflt[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) { const Cand &m = c[j0 + u < m_hi ? j0 + u : m_hi - 1]; jpos[u] = m.pos; jrid[u] = m.rid; jrev[u] = m.reversed; jlap[u] = m.lap2; jflt[u] = m.in_filtered; }
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				if (j0 + u >= m_hi || !jflt[u]) continue;
-				bool pair = false;
-				if (irev != jrev[u] && irid == jrid[u]) { const int64_t dist = irev ? ipos - jpos[u] : jpos[u] - ipos; pair = dist >= -35 && dist < 750; } // cand_is_pair
-				const int v = ilap + jlap[u] + (pair ? 0 : pen2);
-				if (!any || v > best2) { best2 = v; any = true; }
-			}
-		}
+		bool any;
+		if (pair_best) { best2 = pair_best[i]; any = best2 != RFA_NO_PAIR; }
+		else any = rfa_pair_best2(c, i, m_lo, m_hi, pen2, &best2);
 		const double bs = any ? 0.5 * best2 + (c[i].active_molecule ? 0.0 : log_mol_pen) : NEG;
 		rfa_top15_push(top, nt, bs);
 	}
@@ -247,6 +261,9 @@ ARX_DEVI int rfa_read_term(const RfaView &v, int S, int T, int read, int sa, int
 }
 
 template <class B>
+#ifndef ARX_RFA_T
+#define ARX_RFA_T(k) do {} while (0)   // diagnostics hook: per-phase clock (tools builds)
+#endif
 ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int n_c, int read0, int do_rfa, int pen_int, int n_seqs,
                          const double *p10h, int32_t *scratch, RfaBarcodeOut *out)
 {
@@ -254,6 +271,7 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 	const int roff0 = roff[0], pen2 = 2 * pen_int; // roff holds batch-global candidate offsets, c is the barcode's slice
 	RfaView v; v.c = c; v.roff = roff; v.roff0 = roff0; v.pen2 = pen2; v.s = &s;
 	int32_t *act = s.act;
+	ARX_RFA_T(0);
 	// R1 tagBestAlignments: per pair the best (candidate, mate candidate) over the filtered lists; exact ties: first pair wins.
 	// A read in a repeat has dozens of candidates and the pair loop is quadratic, so the inner loop runs per CANDIDATE (all
 	// lanes busy whatever the read), the pick per pair afterwards.
@@ -283,6 +301,7 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 	});
 	if (!do_rfa) { blk.single([&]() { out->dna_len = 0; out->n_mol = 0; }); return; }
 
+	ARX_RFA_T(1);
 	// R2 inferMolecules: filtered candidates, contigs in first-seen order, sorted by position, split at gaps > 50 kb
 	const int P = rfa_pow2ceil(n_c);
 	blk.pfor(n_seqs + 2 > 16 ? n_seqs + 2 : 16, [&](int q) { if (q < n_seqs + 2) s.first_seen[q] = 0x7fffffff; if (q < 16) s.hdr[q] = 0; });
@@ -292,7 +311,9 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 		s.ord[i] = i < n_c ? i : -1;
 		s.skey[i] = f ? ((uint64_t)ARX_LOAD_SHARED(&s.first_seen[c[i].rid + 1]) << 36) | (uint64_t)(c[i].pos + 1) : ~(uint64_t)0;
 	});
+	ARX_RFA_T(2);
 	blk.sort_kv(s.skey, s.ord, P);
+	ARX_RFA_T(3);
 	const int m_c = ARX_LOAD_SHARED(&s.hdr[0]);
 	blk.pfor(m_c, [&](int t) {
 		const int i = s.ord[t];
@@ -319,23 +340,18 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 		}
 		gval[a] = val;
 	});
-	blk.pfor(n_reads, [&](int r) {
-		const int lo = roff[r] - roff0, hi = roff[r + 1] - roff0;
-		for (int i = lo; i < hi; ++i) {
-			if (!c[i].in_filtered) continue;
-			const int m = c[i].mol;
-			bool leader = true;
-			for (int k = lo; k < i; ++k) if (c[k].in_filtered && c[k].mol == m) { leader = false; break; }
-			if (!leader) continue;
-			int best = -1, bs = 0;
-			for (int a = i; a < hi; ++a) {
-				if (!c[a].in_filtered || c[a].mol != m) continue;
-				const int val = gval[a];
-				const bool before = best >= 0 && (c[a].pos < c[best].pos); // a > best in index, so it ranks first only on a smaller position
-				if (best < 0 || val > bs || (val == bs && before)) { bs = val; best = a; }
-			}
-			c[best].best_in_mol = 1;
+	blk.pfor(n_c, [&](int i) { // per candidate, not per read: a read in a repeat has a hundred candidates in as many molecules
+		if (!c[i].in_filtered) return;
+		const int r = c[i].read - read0, lo = roff[r] - roff0, hi = roff[r + 1] - roff0, m = c[i].mol;
+		for (int k = lo; k < i; ++k) if (c[k].in_filtered && c[k].mol == m) return; // not the first of its (read, molecule) group
+		int best = -1, bs = 0;
+		for (int a = i; a < hi; ++a) {
+			if (!c[a].in_filtered || c[a].mol != m) continue;
+			const int val = gval[a];
+			const bool before = best >= 0 && (c[a].pos < c[best].pos); // a > best in index, so it ranks first only on a smaller position
+			if (best < 0 || val > bs || (val == bs && before)) { bs = val; best = a; }
 		}
+		c[best].best_in_mol = 1;
 	});
 	// scrapMolecules: molecules holding an active alignment are renumbered in order; the others disappear
 	const int cnt = blk.exclusive_scan(s.has_active, s.excl, n_mol0);
@@ -357,6 +373,7 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 	blk.pfor(cnt, [&](int m) { s.cursor[m] = s.mol_goff[m]; });
 	blk.pfor(n_c, [&](int i) { if (s.spot[i] >= 0) s.grp_read[ARX_ATOMIC_ADD(&s.cursor[s.spot[i]], 1)] = c[i].read - read0; });
 
+	ARX_RFA_T(4);
 	// one sweep of fastScore(S, *) over the active reads of S: ach/num per sink molecule
 	auto sweep = [&](int S) {
 		blk.pfor(cnt, [&](int T) { s.ach[T] = 0; s.num[T] = 0; });
@@ -411,6 +428,7 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 			ARX_ATOMIC_ADD(&s.mol_nact[S], -1); ARX_ATOMIC_INC(&s.mol_nact[T]);
 		});
 	}
+	ARX_RFA_T(5);
 	// R6 method 2: sum_move += 10^fastScore(S, T), T ascending, for every active alignment of S that has a spot in T
 	for (int S = 0; S < cnt; ++S) {
 		if (ARX_LOAD_SHARED(&s.mol_nact[S]) == 0) continue;
@@ -431,6 +449,7 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 			c[sa].sum_move = sum;
 		});
 	}
+	ARX_RFA_T(6);
 	// setMoleculeConfidences + updateAlignmentsMoleculeStatus + the DNA length of calculateLogMoleculePenalty (all terms are integers)
 	blk.pfor(cnt, [&](int m) { s.m_soft[m] = 0; s.m_lo[m] = 0x7fffffffffffffffLL; s.m_hi[m] = -1; s.m_len[m] = 0; });
 	blk.pfor(n_reads, [&](int r) {
@@ -452,6 +471,7 @@ ARX_DEV void rfa_barcode(B &blk, Cand *c, const int32_t *roff, int n_reads, int 
 	});
 	blk.pfor(m_c, [&](int t) { Cand &x = c[s.ord[t]]; if (x.mol >= 0) x.active_molecule = s.flag[x.mol]; });
 	blk.single([&]() { out->dna_len = cnt > 0 ? 1000.0 + (double)ARX_LOAD_SHARED(dna) : 0.0; out->n_mol = cnt; });
+	ARX_RFA_T(7);
 }
 
 } // namespace arx

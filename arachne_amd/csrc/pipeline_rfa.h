@@ -30,16 +30,25 @@ struct KRfa { // one barcode per workgroup
 	}
 };
 
+struct KMapqPair { // one candidate per lane: its best pair score over the mate's candidates (the quadratic part of estimateMapQualities)
+	const Cand *cands; const int32_t *cand_off; int penalty; int32_t *pair_best;
+	ARX_DEV void operator()(int i, int) const
+	{
+		int best2 = 0;
+		const int mr = cands[i].read ^ 1;
+		pair_best[i] = (cands[i].in_filtered && rfa_pair_best2(cands, i, cand_off[mr], cand_off[mr + 1], 2 * penalty, &best2)) ? best2 : RFA_NO_PAIR;
+	}
+};
 struct KMapq { // one read per lane: MAPQ of its active candidate; values a few ulp could change are queued for the host
 	Cand *cands; const int32_t *cand_off; const int32_t *lens; const int32_t *bc_read_off; int n_barcodes; const double *log_mol_pen;
-	int penalty; const int64_t *cen_start, *cen_end; double guard; int32_t *flagged, *n_flagged;
+	int penalty; const int64_t *cen_start, *cen_end; double guard; int32_t *flagged, *n_flagged; const int32_t *pair_best;
 	ARX_DEV void operator()(int r, int) const
 	{
 		int lo = 0, hi = n_barcodes;
 		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bc_read_off[mid] <= r) lo = mid; else hi = mid; }
 		const int mr = r ^ 1;
 		int a; double largest;
-		const double v = rfa_mapq_value(cands, cand_off[r], cand_off[r + 1], cand_off[mr], cand_off[mr + 1], lens[r], log_mol_pen[lo], penalty, &a, &largest);
+		const double v = rfa_mapq_value(cands, cand_off[r], cand_off[r + 1], cand_off[mr], cand_off[mr + 1], lens[r], log_mol_pen[lo], penalty, &a, &largest, pair_best);
 		cands[a].mapq = rfa_mapq_final(v, cands[a], cen_start, cen_end); // the mate's lane reads other fields of this record, never mapq
 		if (rfa_mapq_needs_host(v, largest, guard)) flagged[ARX_ATOMIC_INC(n_flagged)] = r;
 	}
@@ -99,6 +108,10 @@ template <class RT> struct RfaStage {
 		if (rfa_small)
 			for (int i = 0; i < n_barcodes; ++i) small[i] = (bro[i + 1] - bro[i] <= 2 * SMALL_LANES && res.cand_off[bro[i + 1]] - res.cand_off[bro[i]] <= SMALL_SORT / 2) ? 1 : 0;
 		rt.launch_block("rfa", n_barcodes, kr, rfa_small ? small.data() : nullptr);
+#ifdef ARX_RFA_STATS
+		{ unsigned long long h[8], z[8] = {0}; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rfa_t), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_rfa_t), z, sizeof z);
+		  fprintf(stderr, "rfa phases over %d barcodes (ticks): R1 %llu  R2-presort %llu  sort %llu  R2-rest %llu  R5 optimize %llu  R6 %llu  tail %llu\n", n_barcodes, h[1], h[2], h[3], h[4], h[5], h[6], h[7]); }
+#endif
 		res.bc.resize(n_barcodes);
 		rt.d2h(res.bc.data(), d_out, sizeof(RfaBarcodeOut) * (size_t)n_barcodes);
 		// calculateLogMoleculePenalty (aligner.go:722-741) with libm on the host: one log10 per barcode
@@ -116,7 +129,10 @@ template <class RT> struct RfaStage {
 		rt.memset0(w.counter, 4);
 		const char *ge = getenv("ARX_MAPQ_GUARD"); // tests widen the guard to push every read through the host path
 		const double guard = ge ? atof(ge) : RFA_MAPQ_GUARD;
-		KMapq km{cands, cand_off, b.lens, d_bro, n_barcodes, d_lmp, penalty, d_cs, d_ce, guard, d_flag, w.counter};
+		int32_t *pair_best = rt.template alloc<int32_t>((size_t)NC + 1);
+		KMapqPair kp{cands, cand_off, penalty, pair_best};
+		rt.launch_wide("mapq_pair", (int)NC, kp);
+		KMapq km{cands, cand_off, b.lens, d_bro, n_barcodes, d_lmp, penalty, d_cs, d_ce, guard, d_flag, w.counter, pair_best};
 		rt.launch_wide("mapq", R, km);
 		const int nf = pipe.read_counter(w);
 		res.n_host_mapq = nf;
