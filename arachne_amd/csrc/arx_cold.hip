@@ -167,6 +167,47 @@ template <> void HipRT::run_chain_heavy<KChain>(const char *nm, int n_reads, con
 #endif
 }
 
+// One read with a long region list per 64-lane workgroup: the list goes to LDS, the wavefront runs mem_sort_dedup_patch on it
+// (w_sort_dedup) unless a pair of regions could get as far as mem_patch_reg's alignment -- then lane 0 runs the one-thread pass on the
+// list in HBM, which nothing has touched yet.
+static __global__ void __launch_bounds__(64) k_dedup_heavy(KDedup f, int32_t *eh_pool)
+{
+	__shared__ Reg lds_list[DEDUP_LDS_REGS];
+	__shared__ WaveScratch ws;
+	__shared__ int next_h;
+	const int lane = threadIdx.x, n_heavy = *f.n_heavy;
+	for (;;) {
+		if (lane == 0) next_h = atomicAdd(f.n_heavy + 1, 1);
+		__syncthreads();
+		const int h = next_h;
+		__syncthreads();
+		if (h >= n_heavy) break;
+		const int r = f.heavy_list[h], g0 = f.occ_off[r], n = f.n_ext[r];
+		{
+			const uint32_t *src = (const uint32_t *)(f.regs + g0);
+			uint32_t *dst = (uint32_t *)lds_list;
+			for (int k = lane; k < n * (int)(sizeof(Reg) / 4); k += 64) dst[k] = src[k];
+		}
+		__syncthreads();
+		const int m = w_sort_dedup(n, lds_list, f.tmp + g0, ws, f.ix.l_pac);
+		if (m == -2) {
+			if (lane == 0) f.one_thread(r, eh_pool + (size_t)blockIdx.x * f.eh_words);
+		} else {
+			for (int i = lane; i < m; i += 64) { Reg x = lds_list[i]; if (x.rid >= 0 && f.ix.ann_alt[x.rid]) x.is_alt = 1; f.regs[g0 + i] = x; }
+			if (lane == 0) { f.clean[r] = n >= 2 ? 2 : 1; f.n_core[r] = m; }
+		}
+		__syncthreads();
+	}
+}
+template <> void HipRT::run_dedup_heavy<KDedup>(const char *nm, int n_reads, const KDedup &f)
+{
+	Scope sc(*this, nm, n_reads);
+	const int blocks = n_cu * 4;
+	int32_t *eh_pool = alloc<int32_t>((size_t)blocks * f.eh_words + 16);
+	hipLaunchKernelGGL(k_dedup_heavy, dim3(blocks), dim3(64), 0, stream, f, eh_pool);
+	ARX_HIP_CHECK(hipGetLastError());
+}
+
 template <class F> struct ColdUsesSlots { static const bool value = true; };
 template <> struct ColdUsesSlots<KRescueStep> { static const bool value = false; }; // no per-slot scratch: may take one item per lane
 template <class F> void HipRT::launch_cold(const char *nm, int n, const F &f) { launch_cold_impl(nm, n, f, !ColdUsesSlots<F>::value); }

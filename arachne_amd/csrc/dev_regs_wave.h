@@ -118,13 +118,15 @@ __device__ int w_squeeze(int n, Reg *a, Reg *tmp, const uint64_t keep[4])
 	return m;
 }
 
-// sort_dedup_patch() of dev_regs.h for query == nullptr (no patching: the mate-rescue call site) and n <= W_SORT_MAX.  The two
+// sort_dedup_patch() of dev_regs.h for n <= W_SORT_MAX, without patching: either because there is none (query == nullptr, the mate-rescue
+// call site: patch_l_pac < 0) or because no pair of regions gets past mem_patch_reg's geometric tests (patch_l_pac = l_pac; -2 is returned
+// if one does, before anything but the first sort has happened to the list in LDS).  The two
 // introsorts stay with lane 0 (their order of equal keys is part of the result) on an index array in LDS; everything around them is
 // spread over the lanes: for the redundancy pass every lane walks the earlier neighbours of its own regions and notes which are
 // redundant with it (R) and which of those score higher (S) -- geometry only, independent of who has been dropped -- and the
 // reference's loop (bwamem.c:443-473) is then replayed on the masks: region i drops its alive redundant neighbours from the nearest
 // down, until one that scores higher drops i instead.
-__device__ int w_sort_dedup(int n, Reg *a, Reg *tmp, WaveScratch &ws)
+__device__ int w_sort_dedup(int n, Reg *a, Reg *tmp, WaveScratch &ws, int64_t patch_l_pac = -1)
 {
 	const int lane = threadIdx.x;
 	if (n <= 1) return n;
@@ -134,6 +136,7 @@ __device__ int w_sort_dedup(int n, Reg *a, Reg *tmp, WaveScratch &ws)
 	__syncthreads();
 	w_permute(n, a, tmp, ws.idx);
 	uint64_t A[4] = {0, 0, 0, 0}; // regions that can still be met as the earlier one of a pair
+	bool may_patch = false;
 	for (int rd = 0; rd < 4; ++rd) {
 		const int i = rd * 64 + lane;
 		bool alive = false;
@@ -151,11 +154,21 @@ __device__ int w_sort_dedup(int n, Reg *a, Reg *tmp, WaveScratch &ws)
 				if ((float)orr > OPT_MASK_LEVEL_REDUN * (float)mr && (float)oq > OPT_MASK_LEVEL_REDUN * (float)mq) {
 					ws.R[i][j >> 6] |= 1ull << (j & 63);
 					if (p.score < q.score) ws.S[i][j >> 6] |= 1ull << (j & 63);
+				} else if (patch_l_pac >= 0 && q.rb < p.rb) { // could mem_patch_reg(q, p) get as far as its alignment?  (bwamem.c:406-421)
+					if (!(q.rb < patch_l_pac && p.rb >= patch_l_pac) && !(q.qb >= p.qb || q.qe >= p.qe || q.re >= p.re)) {
+						int w = (int)((q.re - p.rb) - (q.qe - p.qb));
+						w = w > 0 ? w : -w;
+						double r = (double)(q.re - p.rb) / (double)(p.re - q.rb) - (double)(q.qe - p.qb) / (double)(p.qe - q.qb);
+						r = r > 0. ? r : -r;
+						if (q.re < p.rb || q.qe < p.qb) { if (!(w > OPT_W << 1 || r >= (double)0.05f)) may_patch = true; }
+						else if (!(w > OPT_W << 2 || r >= (double)(0.05f * 2))) may_patch = true;
+					}
 				}
 			}
 		}
 		A[rd] = __ballot(alive);
 	}
+	if (__ballot(may_patch)) return -2; // the caller takes the one-thread pass on the untouched list
 	__syncthreads();
 	for (int i = 1; i < n; ++i) { // every lane replays the same loop on the masks
 		uint64_t c[4], st = 0;

@@ -224,6 +224,8 @@ struct HipRT {
 	// chaining of the reads with many seed occurrences, one wavefront per read on a working set in LDS (arx_cold.hip); f.heavy_list / f.n_heavy
 	bool chain_heavy_ok() const { return !(getenv("ARX_CHAIN_HEAVY") && atoi(getenv("ARX_CHAIN_HEAVY")) == 0); }
 	template <class F> void run_chain_heavy(const char *nm, int n_reads, const F &f);
+	bool dedup_heavy_ok() const { return !(getenv("ARX_DEDUP_HEAVY") && atoi(getenv("ARX_DEDUP_HEAVY")) == 0); }
+	template <class F> void run_dedup_heavy(const char *nm, int n_reads, const F &f); // likewise the region lists of such reads (f.eh_words ints of scratch per workgroup)
 	template <class F> void launch_cold_impl(const char *nm, int n, const F &f, bool wide = false)
 	{
 		if (n <= 0) return;

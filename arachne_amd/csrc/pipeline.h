@@ -264,18 +264,27 @@ struct KExtend {
 	}
 };
 
+// Reads with long region lists (32+ regions: reads in high-copy repeats) leave the thread-per-read kernel for k_dedup_heavy
+// (arx_cold.hip): one wavefront per read, the list in LDS (dev_regs_wave.h: w_sort_dedup).
+constexpr int DEDUP_HEAVY_MIN = 32, DEDUP_LDS_REGS = 256;
 struct KDedup {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *occ_off; const int32_t *n_ext; Reg *regs, *tmp; int32_t *idx;
 	int32_t *eh; int eh_words; int32_t *n_core;
 	int32_t *clean; // what the rescue stage may assume about the list (matesw_apply): 2 = went through the pass with >= 2 regions and nothing was merged,
 	                // so it is a fixed point of the pass mem_matesw repeats; 1 = fewer than two regions; 0 = a merge happened, nothing is known
+	int32_t *heavy_list, *n_heavy; int32_t heavy_min; // null: every read by its own thread
 	ARX_DEV void operator()(int r, int slot) const
+	{
+		if (heavy_list && n_ext[r] >= heavy_min && n_ext[r] <= DEDUP_LDS_REGS) { heavy_list[ARX_ATOMIC_ADD(n_heavy, 1)] = r; return; }
+		one_thread(r, eh + (size_t)slot * eh_words);
+	}
+	ARX_DEV void one_thread(int r, int32_t *eh_slot) const
 	{
 		const int g0 = occ_off[r];
 		int n = n_ext[r];
 		int32_t patched = 0;
 		clean[r] = n >= 2 ? 2 : 1;
-		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh + (size_t)slot * eh_words, &patched);
+		n = sort_dedup_patch(ix, bases + base_off[r], n, regs + g0, tmp + g0, idx + g0, eh_slot, &patched);
 		if (patched) clean[r] = 0;
 		for (int i = 0; i < n; ++i) { Reg &p = regs[g0 + i]; if (p.rid >= 0 && ix.ann_alt[p.rid]) p.is_alt = 1; }
 		n_core[r] = n;
@@ -617,8 +626,11 @@ public:
 		KExtGather kg{w.occ_off, w.n_chain, chain_off, w.cout, w.est, pool, w.regs, n_ext};
 		rt.launch_wide("ext_gather", R, kg);
 		if (trace) { fprintf(stderr, "[arx] dedup\n"); fflush(stderr); }
-		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, w.core_clean};
+		KDedup kd{ix, b.bases, b.base_off, b.lens, w.occ_off, n_ext, w.regs, w.rtmp, w.idx, w.eh, eh_words, w.n_core, w.core_clean, nullptr, nullptr,
+		          getenv("ARX_DEDUP_HEAVY_MIN") ? atoi(getenv("ARX_DEDUP_HEAVY_MIN")) : DEDUP_HEAVY_MIN};
+		if (rt.dedup_heavy_ok()) { kd.heavy_list = rt.template alloc<int32_t>(R + 4); kd.n_heavy = kd.heavy_list + R; rt.memset0(kd.n_heavy, 16); }
 		rt.launch_cold("dedup", R, kd);
+		if (kd.heavy_list) rt.run_dedup_heavy("dedup_heavy", R, kd);
 	}
 
 	// ---- stage 5: mate rescue rounds

@@ -87,6 +87,8 @@ def test_heavy_item_split_hostsim(built, monkeypatch):
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
     monkeypatch.setenv("ARX_SIM_RESCUE_HEAVY", "1")
     monkeypatch.setenv("ARX_SIM_CHAIN_HEAVY", "1")
+    monkeypatch.setenv("ARX_SIM_DEDUP_HEAVY", "1")
+    monkeypatch.setenv("ARX_DEDUP_HEAVY_MIN", "3")
     monkeypatch.setenv("ARX_RESCUE_HEAVY_MIN", "6")
     monkeypatch.setenv("ARX_CHAIN_HEAVY_MIN", "12")
     g, rs = _segdup_workload(73, 900_000, 50, 3, 50)
@@ -110,10 +112,52 @@ def test_long_lists_with_exact_ties_wave_rescue_gpu(built, monkeypatch, heavy_mi
     kernels; 48 / 64 are the product settings."""
     monkeypatch.setenv("ARX_RESCUE_HEAVY_MIN", heavy_min)
     monkeypatch.setenv("ARX_CHAIN_HEAVY_MIN", "4" if heavy_min == "6" else "64")       # likewise the one-wavefront-per-read chaining kernel
+    monkeypatch.setenv("ARX_DEDUP_HEAVY_MIN", "2" if heavy_min == "6" else "32")       # and the one that de-duplicates a read's regions
     g = synth.make_genome(75, [2_000_000, 30000], repeat_families=[(80, 3000, 0.0), (50, 2000, 0.003)], n_runs=1)
     rs = synth.make_reads(76, g, 6, 150, molecule_len=10000, molecules_per_barcode=5)
     dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, stages=True)
     assert np.diff(ob["reg_off"]).max() >= 40
+
+
+def _deletion_reads(seed, n_pairs):
+    """Pairs whose first read skips 4-190 bp of the reference in its middle: two collinear regions from two chains, the pairs of regions
+    mem_sort_dedup_patch hands to mem_patch_reg (bwamem.c:406-435, 463-470).  Its tests on the gap ratio let only the short gaps through
+    to the alignment; the long ones stay two regions."""
+    g = synth.make_genome(seed, [600_000], repeat_families=[(8, 3000, 0.02)], n_runs=0)
+    rs = synth.make_reads(seed + 1, g, 2, n_pairs, molecule_len=20000, molecules_per_barcode=4, indel_rate=0.0)
+    rng = np.random.default_rng(seed + 2)
+    ref = g.seqs[0]
+    for i in range(0, rs.n_pairs, 2):                                # every second pair: R1 rebuilt with a deletion, R2 a proper mate
+        p = int(rng.integers(1000, len(ref) - 2000))
+        d = int(rng.integers(110, 191)) if rng.random() < 0.5 else int(rng.integers(4, 12))
+        cut = int(rng.integers(60, 91))
+        fwd = np.concatenate([ref[p:p + cut], ref[p + cut + d:p + d + 150]])
+        if rng.random() < 0.5:
+            r1, r2 = fwd, synth._revcomp(ref[p + d + 250:p + d + 400])
+        else:                                                        # the pair on the other strand
+            r1, r2 = synth._revcomp(fwd), ref[p - 400:p - 250].copy()
+        rs.seqs[2 * i], rs.seqs[2 * i + 1] = r1, r2
+    return g, rs
+
+
+def test_deletion_reads_collinear_regions_hostsim(built, monkeypatch):
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    monkeypatch.setenv("ARX_SIM_DEDUP_HEAVY", "1")
+    monkeypatch.setenv("ARX_DEDUP_HEAVY_MIN", "2")
+    g, rs = _deletion_reads(83, 60)
+    dev, cands, ob = _run_and_check(SIM, g, rs)
+    assert int((np.diff(dev["reg_off"]) >= 2).sum()) >= 10             # reads that kept both regions
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heavy_min", ["2", "32"])
+def test_deletion_reads_collinear_regions_gpu(built, monkeypatch, heavy_min):
+    """The same through the GPU library; with the threshold at 2 every read with two regions takes the one-wavefront-per-read
+    de-duplication kernel, whose probe must send the mergeable ones to the one-thread pass (dev_regs_wave.h: w_sort_dedup)."""
+    monkeypatch.setenv("ARX_DEDUP_HEAVY_MIN", heavy_min)
+    g, rs = _deletion_reads(84, 300)
+    dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs)
+    assert int((np.diff(dev["reg_off"]) >= 2).sum()) >= 50
 
 
 def _one_barcode(seed, genome_len, n_pairs):
