@@ -401,6 +401,7 @@ def main():
     # streams overlap, and the elapsed time of a launch there includes what it waits for)
     ref.kernel_times_reset(True)
     for b in batches:
+        b.run(api.STAGE_SEED)
         b.run(api.STAGE_ALN)
         if not args.no_rfa:
             b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
