@@ -12,6 +12,11 @@ __device__ unsigned long long g_cstat[24];
 #include "pipeline.h"
 #include "dev_regs_wave.h"
 #include "dev_chain_wave.h"
+#ifdef ARX_WSORT_CHECK
+static void wsort_report(hipStream_t st, const char *who) { unsigned long long h[2]; hipStreamSynchronize(st); hipMemcpyFromSymbol(h, HIP_SYMBOL(arx::g_wsort_bad), sizeof h); fprintf(stderr, "wsort check after %s: %llu sorts so far, %llu differ from ks_introsort\n", who, h[1], h[0]); }
+#else
+static void wsort_report(hipStream_t, const char *) {}
+#endif
 
 namespace arx {
 // One heavy pair per 64-lane workgroup: the lanes copy both region lists into LDS, the wavefront replays the rescue state machine on
@@ -82,6 +87,7 @@ template <> void HipRT::run_rescue_heavy<KRescueStep>(const char *nm, int n, con
 	const int blocks = n < n_cu * 8 ? n : n_cu * 8;
 	hipLaunchKernelGGL(k_rescue_heavy, dim3(blocks), dim3(64), 0, stream, f, list, n, wave);
 	ARX_HIP_CHECK(hipGetLastError());
+	wsort_report(stream, nm);
 #ifdef ARX_WAVE_STATS
 	{ unsigned long long h[24], z[24] = {0}; hipStreamSynchronize(stream); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wstat), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_wstat), z, sizeof z);
 	  fprintf(stderr, "wstat inserts %llu fast %llu gone %llu tie %llu unclean %llu noinsert-general %llu long %llu | worst block: total %llu fast %llu general %llu skip %llu (100 MHz ticks) n0 %llu n1 %llu | sums: total %llu fast %llu general %llu skip %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[11], h[12] >> 32, h[12] & 0xffffffff, h[13], h[14], h[15], h[16]); }
@@ -206,6 +212,7 @@ template <> void HipRT::run_dedup_heavy<KDedup>(const char *nm, int n_reads, con
 	int32_t *eh_pool = alloc<int32_t>((size_t)blocks * f.eh_words + 16);
 	hipLaunchKernelGGL(k_dedup_heavy, dim3(blocks), dim3(64), 0, stream, f, eh_pool);
 	ARX_HIP_CHECK(hipGetLastError());
+	wsort_report(stream, nm);
 }
 
 template <class F> struct ColdUsesSlots { static const bool value = true; };

@@ -6,7 +6,8 @@
 // working set sits in LDS and the steps that do not depend on each other are spread over the lanes:
 //   * mem_chain's loop itself (bwamem.c:273-307) is a chain of dependent B-tree updates: lane 0 runs chain_build() of dev_chain.h;
 //   * the chains' weights (mem_chain_weight): one chain per lane;
-//   * ranking by weight: lane 0, klib's introsort as everywhere (its order of equal weights is part of the result);
+//   * ranking by weight: klib's introsort reproduced by the wavefront (w_introsort, dev_regs_wave.h; its order of equal weights is part of
+//     the result), lane 0 alone for more than 256 chains;
 //   * mem_chain_flt's loop (bwamem.c:340-371): chain i against the chains kept so far, 64 of them per step -- each lane tests one kept
 //     chain, ballots give the first kept chain that drops i; `first` is set on the chains the reference's loop would have visited
 //     (up to and including that one), exactly as the serial loop does;
@@ -14,6 +15,7 @@
 // Results are those of chain_and_filter() bit for bit.
 #pragma once
 #include "dev_chain.h"
+#include "dev_regs_wave.h" // w_introsort
 
 namespace arx {
 
@@ -39,8 +41,13 @@ __device__ int w_chain_and_filter(const IndexView &ix, int len, const Biv *intv,
 	if (n <= 0) return n;
 	for (int i = lane; i < n; i += 64) { Chain &c = ctmp[ord[i]]; c.first = -1; c.kept = 0; c.w = chain_weight(c, occ, next); }
 	__syncthreads();
-	if (lane == 0) { ARX_CHAIN_T(2); WeightGt gt; gt.c = ctmp; ks_introsort(n, ord, gt); ARX_CHAIN_T(3); }
-	__syncthreads();
+	if (lane == 0) ARX_CHAIN_T(2);
+	{
+		WeightGt gt; gt.c = ctmp;
+		if (n <= W_SORT_MAX) w_introsort(n, ord, gt, qb_, qe_); // the rank arrays are filled after the sort
+		else { if (lane == 0) ks_introsort(n, ord, gt); __syncthreads(); }
+	}
+	if (lane == 0) ARX_CHAIN_T(3);
 	for (int i = lane; i < n; i += 64) {
 		const Chain &c = ctmp[ord[i]];
 		qb_[i] = occ[c.head].qbeg; qe_[i] = occ[c.tail].qbeg + occ[c.tail].len; w_[i] = c.w; alt_[i] = c.is_alt; first_[i] = -1;

@@ -73,9 +73,106 @@ __device__ int w_rescue_enumerate(const IndexView &ix, int pair, const int *lens
 	return cnt;
 }
 
-// LDS scratch of the wave's general pass (lists of up to W_SORT_MAX regions)
 #define W_SORT_MAX 256
-struct WaveScratch { int idx[W_SORT_MAX]; uint64_t R[W_SORT_MAX][4], S[W_SORT_MAX][4]; };
+// klib's ks_introsort (arx_dev.h) on an index array of up to W_SORT_MAX entries in LDS, by the whole wavefront, with klib's result: the
+// permutation depends on how the algorithm orders equal keys, so every step is reproduced, only faster.
+//   * One partition step (median of three to the end of the range, then `do ++i while (a[i] < rp)` / `do --j while (i <= j && rp < a[j])`
+//     / swap) visits every position of the range once: i stops at the positions whose key is not below the pivot ("left stops", ascending),
+//     j at those whose key is not above it ("right stops", descending); the k-th left stop is swapped with the k-th right stop as long as
+//     it lies left of it, and swapped positions are never looked at again.  So the lanes classify the range's positions side by side,
+//     ballots rank the stops, m = the number of pairs in order, the m swaps are independent, and the scan ends at
+//     i = min(left stop m+1, right stop m) (the value swapped into right stop m stops i as well); the pivot goes to i.  The first
+//     position of the range is never examined (i starts at s + 1), exactly as in klib.
+//   * Ranges of 16 or fewer are left to the final insertion sort, which is a stable sort of the whole array: every lane counts, for its
+//     elements, the elements with a smaller key plus the equal ones before it.
+//   * The range stack and the depth budget (comb sort when it runs out: lane 0, as rare as in klib) are wave-uniform scalars.
+// lpos / rpos: scratch, W_SORT_MAX ints of LDS each.
+template <class LT> __device__ void w_introsort(int n, int *a, LT lt, int *lpos, int *rpos)
+{
+	const int lane = threadIdx.x;
+	if (n < 1) return;
+	if (n == 2) { if (lane == 0 && lt(a[1], a[0])) { const int x = a[0]; a[0] = a[1]; a[1] = x; } __syncthreads(); return; }
+	int st_l[24], st_r[24], st_d[24], top = 0; // a range is pushed only if longer than 16 and the shorter side is continued with: depth <= log2(n / 16) + 1
+	int d, s = 0, t = n - 1;
+	for (d = 2; (1 << d) < n; ++d) {}
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			--d;
+			if (d == 0) {
+				if (lane == 0) ks_combsort(t - s + 1, a + s, lt);
+				__syncthreads();
+				t = s;
+				continue;
+			}
+			int k = s + ((t - s) >> 1) + 1;
+			{
+				const int vk = a[k], vi = a[s], vj = a[t];
+				if (lt(vk, vi)) { if (lt(vk, vj)) k = t; }
+				else k = lt(vj, vi) ? s : t;
+			}
+			const int rp = a[k];
+			__syncthreads(); // every lane has read a[k], a[t]
+			if (k != t && lane == 0) { a[k] = a[t]; a[t] = rp; }
+			__syncthreads();
+			int n_l = 0, n_r = 0;
+			for (int x0 = s + 1; x0 <= t; x0 += 64) {
+				const int x = x0 + lane;
+				bool lf = false, rf = false;
+				if (x <= t) { const int v = a[x]; lf = !lt(v, rp); rf = x < t && !lt(rp, v); }
+				const uint64_t bl = __ballot(lf), br = __ballot(rf), below = (1ull << lane) - 1;
+				if (lf) lpos[n_l + __builtin_popcountll(bl & below)] = x;
+				if (rf) rpos[n_r + __builtin_popcountll(br & below)] = x;
+				n_l += __builtin_popcountll(bl); n_r += __builtin_popcountll(br);
+			}
+			__syncthreads();
+			int m = 0; // pairs (k-th left stop, k-th right stop from the top) that are in order: a prefix
+			const int n_p = n_l < n_r ? n_l : n_r;
+			for (int k0 = 0; k0 < n_p; k0 += 64) {
+				const int kk = k0 + lane;
+				const bool ok = kk < n_p && lpos[kk] < rpos[n_r - 1 - kk];
+				const uint64_t b = __ballot(ok);
+				m += __builtin_popcountll(b);
+				if (b != ~0ull) break;
+			}
+			int i = lpos[m];
+			if (m > 0) { const int rm = rpos[n_r - m]; i = rm < i ? rm : i; }
+			__syncthreads();
+			for (int kk = lane; kk < m; kk += 64) { const int x = lpos[kk], y = rpos[n_r - 1 - kk], v = a[x]; a[x] = a[y]; a[y] = v; }
+			__syncthreads();
+			if (lane == 0) { const int v = a[i]; a[i] = a[t]; a[t] = v; }
+			__syncthreads();
+			if (i - s > t - i) {
+				if (i - s > 16) { st_l[top] = s; st_r[top] = i - 1; st_d[top] = d; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { st_l[top] = i + 1; st_r[top] = t; st_d[top] = d; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else if (top == 0) break;
+		else { --top; s = st_l[top]; t = st_r[top]; d = st_d[top]; }
+	}
+	// ks_insertsort over the whole array = its stable sort
+	int mine[W_SORT_MAX / 64], dest[W_SORT_MAX / 64];
+#pragma unroll
+	for (int u = 0; u < W_SORT_MAX / 64; ++u) {
+		const int x = u * 64 + lane;
+		mine[u] = -1; dest[u] = 0;
+		if (x < n) {
+			const int v = a[x];
+			int cnt = 0;
+			for (int y = 0; y < n; ++y) { const int w = a[y]; cnt += (lt(w, v) || (y < x && !lt(v, w))) ? 1 : 0; }
+			mine[u] = v; dest[u] = cnt;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < W_SORT_MAX / 64; ++u) if (mine[u] >= 0) a[dest[u]] = mine[u];
+	__syncthreads();
+}
+
+// LDS scratch of the wave's general pass (lists of up to W_SORT_MAX regions)
+struct WaveScratch { int idx[W_SORT_MAX]; uint64_t R[W_SORT_MAX][4], S[W_SORT_MAX][4]; }; // R / S double as w_introsort's scratch (not live during a sort)
 
 // ma[at..n) one place up, 64 records per step from the top, then ma[at] = b
 __device__ void w_insert_at(Reg *ma, int n, int at, const Reg &b)
@@ -118,6 +215,21 @@ __device__ int w_squeeze(int n, Reg *a, Reg *tmp, const uint64_t keep[4])
 	return m;
 }
 
+// the sort of the general pass: w_introsort, or (ARX_WSORT_SERIAL, A/B builds) lane 0 running ks_introsort; ARX_WSORT_CHECK runs both and
+// flags a difference in ws.idx[W_SORT_MAX - 1] = -1 ... kept out of the product build
+#if defined(ARX_WSORT_SERIAL)
+#define W_SORT(n, idx, lt, ws) do { if (threadIdx.x == 0) ks_introsort((n), (idx), (lt)); __syncthreads(); } while (0)
+#elif defined(ARX_WSORT_CHECK)
+__device__ unsigned long long g_wsort_bad[2];
+#define W_SORT(n, idx, lt, ws) do { int *chk_ = (int *)(ws).S; for (int q_ = threadIdx.x; q_ < (n); q_ += 64) chk_[q_] = (idx)[q_]; __syncthreads(); \
+	if (threadIdx.x == 0) ks_introsort((n), chk_, (lt)); __syncthreads(); \
+	w_introsort((n), (idx), (lt), (int *)(ws).R, (int *)(ws).R + W_SORT_MAX); \
+	bool bad_ = false; for (int q_ = threadIdx.x; q_ < (n); q_ += 64) bad_ = bad_ || chk_[q_] != (idx)[q_]; \
+	if (threadIdx.x == 0) atomicAdd(&g_wsort_bad[1], 1ull); if (__ballot(bad_) && threadIdx.x == 0) atomicAdd(&g_wsort_bad[0], 1ull); __syncthreads(); } while (0)
+#else
+#define W_SORT(n, idx, lt, ws) w_introsort((n), (idx), (lt), (int *)(ws).R, (int *)(ws).R + W_SORT_MAX)
+#endif
+
 // sort_dedup_patch() of dev_regs.h for n <= W_SORT_MAX, without patching: either because there is none (query == nullptr, the mate-rescue
 // call site: patch_l_pac < 0) or because no pair of regions gets past mem_patch_reg's geometric tests (patch_l_pac = l_pac; -2 is returned
 // if one does, before anything but the first sort has happened to the list in LDS).  The two
@@ -132,8 +244,7 @@ __device__ int w_sort_dedup(int n, Reg *a, Reg *tmp, WaveScratch &ws, int64_t pa
 	if (n <= 1) return n;
 	for (int i = lane; i < n; i += 64) ws.idx[i] = i;
 	__syncthreads();
-	if (lane == 0) { RegReLt lt; lt.r = a; ks_introsort(n, ws.idx, lt); }
-	__syncthreads();
+	{ RegReLt lt; lt.r = a; W_SORT(n, ws.idx, lt, ws); }
 	w_permute(n, a, tmp, ws.idx);
 	uint64_t A[4] = {0, 0, 0, 0}; // regions that can still be met as the earlier one of a pair
 	bool may_patch = false;
@@ -200,8 +311,7 @@ __device__ int w_sort_dedup(int n, Reg *a, Reg *tmp, WaveScratch &ws, int64_t pa
 	n = w_squeeze(n, a, tmp, keep);
 	for (int i = lane; i < n; i += 64) ws.idx[i] = i;
 	__syncthreads();
-	if (lane == 0) { RegScoreLt lt; lt.r = a; ks_introsort(n, ws.idx, lt); }
-	__syncthreads();
+	{ RegScoreLt lt; lt.r = a; W_SORT(n, ws.idx, lt, ws); }
 	w_permute(n, a, tmp, ws.idx);
 	for (int rd = 0; rd < 4; ++rd) { // identical (score, rb, qb) as the region before: dropped; region 0 always stays (bwamem.c:480-487)
 		const int i = rd * 64 + lane;
