@@ -82,11 +82,13 @@ static __global__ void __launch_bounds__(64) k_rescue_heavy(KRescueStep f, const
 template <> void HipRT::run_rescue_heavy<KRescueStep>(const char *nm, int n, const int32_t *list, const KRescueStep &f)
 {
 	if (n <= 0) return;
-	Scope sc(*this, nm, n);
 	static const int wave = getenv("ARX_RESCUE_WAVE") ? atoi(getenv("ARX_RESCUE_WAVE")) : 1;
 	const int blocks = n < n_cu * 8 ? n : n_cu * 8;
-	hipLaunchKernelGGL(k_rescue_heavy, dim3(blocks), dim3(64), 0, stream, f, list, n, wave);
-	ARX_HIP_CHECK(hipGetLastError());
+	on_aux([&]() { // beside the thread-per-pair launch of the same round (the caller joins before it reads the round's task count)
+		Scope sc(*this, nm, n);
+		hipLaunchKernelGGL(k_rescue_heavy, dim3(blocks), dim3(64), 0, stream, f, list, n, wave);
+		ARX_HIP_CHECK(hipGetLastError());
+	});
 	wsort_report(stream, nm);
 #ifdef ARX_WAVE_STATS
 	{ unsigned long long h[24], z[24] = {0}; hipStreamSynchronize(stream); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wstat), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_wstat), z, sizeof z);
@@ -163,9 +165,10 @@ template <> void HipRT::run_chain_heavy<KChain>(const char *nm, int n_reads, con
 	static bool attr_set = false;
 	if (!attr_set) { ARX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
 	// f.n_heavy[0]: the list's length (stays on the device), [1] and [2]: the two launches' cursors into it
-	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); // the long ones first
+	on_aux([&]() { hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); }); // the few long ones beside the rest
 	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu * 4), dim3(64), lds_s, stream, f, 0, CHAIN_LDS_SMALL, f.n_heavy + 1, wave);
 	ARX_HIP_CHECK(hipGetLastError());
+	aux_join();
 #ifdef ARX_CHAIN_STATS
 	{ unsigned long long h[24], z[24] = {0}; hipStreamSynchronize(stream); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cstat), sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_cstat), z, sizeof z);
 	  fprintf(stderr, "cstat reads %llu | sums (100 MHz ticks): chaining %llu traverse+weights %llu sort %llu filter %llu output %llu | worst read: total %llu = %llu %llu %llu %llu %llu, n_occ %llu kept %llu\n",

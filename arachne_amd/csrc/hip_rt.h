@@ -44,6 +44,24 @@ struct HipRT {
 	static const char *name() { return "hip:gfx950"; }
 	static BwtSaFn bwt_sa_fn() { return product_bwt_sa; } // arx_index_build: the suffix sort runs in HBM
 	hipStream_t stream = 0;
+	// side stream for launches that are one wavefront's tail (the heavy-item kernels): they run beside the launches that follow on the main
+	// stream until aux_join()
+	hipStream_t aux = 0; hipEvent_t ev_fork = 0, ev_join = 0; bool aux_pending = false;
+	bool aux_ok = !(getenv("ARX_AUX_STREAM") && atoi(getenv("ARX_AUX_STREAM")) == 0);
+	template <class L> void on_aux(L f)
+	{
+		if (!aux_ok) { f(); return; }
+		if (!aux) {
+			ARX_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+			ARX_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); ARX_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+		}
+		ARX_HIP_CHECK(hipEventRecord(ev_fork, stream)); ARX_HIP_CHECK(hipStreamWaitEvent(aux, ev_fork, 0));
+		hipStream_t main_stream = stream;
+		stream = aux; f(); stream = main_stream;
+		ARX_HIP_CHECK(hipEventRecord(ev_join, aux));
+		aux_pending = true;
+	}
+	void aux_join() { if (aux_pending) { ARX_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0)); aux_pending = false; } }
 	int n_cu = 256;
 	bool timing = false;
 	std::map<std::string, KernelTimer> tm;
@@ -77,6 +95,7 @@ struct HipRT {
 		if (stage_buf) (void)hipHostFree(stage_buf);
 		for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 		for (auto e : free_events) (void)hipEventDestroy(e);
+		if (aux) { hipStreamDestroy(aux); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
 		if (stream) hipStreamDestroy(stream);
 	}
 	// Work memory of a batch comes from a per-runtime arena: slabs obtained once with hipMalloc, bump-allocated, reset as

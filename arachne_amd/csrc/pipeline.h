@@ -658,8 +658,9 @@ public:
 		for (int round = 0;; ++round) {
 			rt.memset0(w.counter, 4);
 			KRescueStep ks{ix, b.lens, w.preg_off, w.pregs, w.ptmp, w.pidx, w.n_regs, w.rst, w.sres, w.stask, w.counter, n_slots, getenv("ARX_RESCUE_NO_AHEAD") ? 1 : 0, (int32_t)(2 * w.P), hv};
+			if (n_heavy > 0) rt.run_rescue_heavy("rescue_heavy", n_heavy, hv_list, ks); // on the side stream: a few wavefronts' worth of work
 			rt.launch_cold("rescue_step", NP, ks);
-			if (n_heavy > 0) rt.run_rescue_heavy("rescue_heavy", n_heavy, hv_list, ks);
+			rt.aux_join();
 			int nt = read_counter(w);
 			if (trace) { fprintf(stderr, "[arx] rescue round %d: %d tasks\n", round, nt); fflush(stderr); }
 			if (nt == 0) {

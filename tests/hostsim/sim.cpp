@@ -112,6 +112,7 @@ struct SimRT {
 	void free(void *p) { ::free(p); }
 	void seed_prepare(const uint8_t *, const int32_t *, const int32_t *, int) {}
 	bool rescue_heavy_ok() const { return getenv("ARX_SIM_RESCUE_HEAVY") != nullptr; } // the host double can run the split (same serial code on the flagged pairs)
+	void aux_join() {}
 	bool dedup_heavy_ok() const { return getenv("ARX_SIM_DEDUP_HEAVY") != nullptr; }
 	template <class F> void run_dedup_heavy(const char *nm, int, const F &f) { tm[nm].calls++; for (int i = 0; i < *f.n_heavy; ++i) f.one_thread(f.heavy_list[i], f.eh); }
 	bool chain_heavy_ok() const { return getenv("ARX_SIM_CHAIN_HEAVY") != nullptr; }
