@@ -87,12 +87,12 @@ __device__ int w_rescue_enumerate(const IndexView &ix, int pair, const int *lens
 //     elements, the elements with a smaller key plus the equal ones before it.
 //   * The range stack and the depth budget (comb sort when it runs out: lane 0, as rare as in klib) are wave-uniform scalars.
 // lpos / rpos: scratch, W_SORT_MAX ints of LDS each.
-template <class LT> __device__ void w_introsort(int n, int *a, LT lt, int *lpos, int *rpos)
+template <int MAXN, class LT> __device__ void w_introsort(int n, int *a, LT lt, int *lpos, int *rpos) // n <= MAXN (a multiple of 64)
 {
 	const int lane = threadIdx.x;
 	if (n < 1) return;
 	if (n == 2) { if (lane == 0 && lt(a[1], a[0])) { const int x = a[0]; a[0] = a[1]; a[1] = x; } __syncthreads(); return; }
-	int st_l[24], st_r[24], st_d[24], top = 0; // a range is pushed only if longer than 16 and the shorter side is continued with: depth <= log2(n / 16) + 1
+	int st_l[24], st_r[24], st_d[24], top = 0; // the longer side of a partition is pushed (if longer than 16), the shorter one continued with: depth <= log2(n / 16) + 1
 	int d, s = 0, t = n - 1;
 	for (d = 2; (1 << d) < n; ++d) {}
 	d <<= 1;
@@ -153,9 +153,9 @@ template <class LT> __device__ void w_introsort(int n, int *a, LT lt, int *lpos,
 		else { --top; s = st_l[top]; t = st_r[top]; d = st_d[top]; }
 	}
 	// ks_insertsort over the whole array = its stable sort
-	int mine[W_SORT_MAX / 64], dest[W_SORT_MAX / 64];
+	int mine[MAXN / 64], dest[MAXN / 64];
 #pragma unroll
-	for (int u = 0; u < W_SORT_MAX / 64; ++u) {
+	for (int u = 0; u < MAXN / 64; ++u) {
 		const int x = u * 64 + lane;
 		mine[u] = -1; dest[u] = 0;
 		if (x < n) {
@@ -167,7 +167,7 @@ template <class LT> __device__ void w_introsort(int n, int *a, LT lt, int *lpos,
 	}
 	__syncthreads();
 #pragma unroll
-	for (int u = 0; u < W_SORT_MAX / 64; ++u) if (mine[u] >= 0) a[dest[u]] = mine[u];
+	for (int u = 0; u < MAXN / 64; ++u) if (mine[u] >= 0) a[dest[u]] = mine[u];
 	__syncthreads();
 }
 
@@ -223,11 +223,11 @@ __device__ int w_squeeze(int n, Reg *a, Reg *tmp, const uint64_t keep[4])
 __device__ unsigned long long g_wsort_bad[2];
 #define W_SORT(n, idx, lt, ws) do { int *chk_ = (int *)(ws).S; for (int q_ = threadIdx.x; q_ < (n); q_ += 64) chk_[q_] = (idx)[q_]; __syncthreads(); \
 	if (threadIdx.x == 0) ks_introsort((n), chk_, (lt)); __syncthreads(); \
-	w_introsort((n), (idx), (lt), (int *)(ws).R, (int *)(ws).R + W_SORT_MAX); \
+	w_introsort<W_SORT_MAX>((n), (idx), (lt), (int *)(ws).R, (int *)(ws).R + W_SORT_MAX); \
 	bool bad_ = false; for (int q_ = threadIdx.x; q_ < (n); q_ += 64) bad_ = bad_ || chk_[q_] != (idx)[q_]; \
 	if (threadIdx.x == 0) atomicAdd(&g_wsort_bad[1], 1ull); if (__ballot(bad_) && threadIdx.x == 0) atomicAdd(&g_wsort_bad[0], 1ull); __syncthreads(); } while (0)
 #else
-#define W_SORT(n, idx, lt, ws) w_introsort((n), (idx), (lt), (int *)(ws).R, (int *)(ws).R + W_SORT_MAX)
+#define W_SORT(n, idx, lt, ws) w_introsort<W_SORT_MAX>((n), (idx), (lt), (int *)(ws).R, (int *)(ws).R + W_SORT_MAX)
 #endif
 
 // sort_dedup_patch() of dev_regs.h for n <= W_SORT_MAX, without patching: either because there is none (query == nullptr, the mate-rescue
