@@ -165,7 +165,8 @@ template <> void HipRT::run_chain_heavy<KChain>(const char *nm, int n_reads, con
 	static bool attr_set = false;
 	if (!attr_set) { ARX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
 	// f.n_heavy[0]: the list's length (stays on the device), [1] and [2]: the two launches' cursors into it
-	on_aux([&]() { hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); }); // the few long ones beside the rest
+	static const int l_div = getenv("ARX_CHAIN_L_DIV") ? atoi(getenv("ARX_CHAIN_L_DIV")) : 1; // the long ones' launch holds 128 KB of LDS per workgroup: on n_cu / l_div CUs
+	on_aux([&]() { hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu / (l_div > 0 ? l_div : 1)), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); }); // the few long ones (beside the rest with ARX_AUX_STREAM=1)
 	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu * 4), dim3(64), lds_s, stream, f, 0, CHAIN_LDS_SMALL, f.n_heavy + 1, wave);
 	ARX_HIP_CHECK(hipGetLastError());
 	aux_join();

@@ -47,7 +47,10 @@ struct HipRT {
 	// side stream for launches that are one wavefront's tail (the heavy-item kernels): they run beside the launches that follow on the main
 	// stream until aux_join()
 	hipStream_t aux = 0; hipEvent_t ev_fork = 0, ev_join = 0; bool aux_pending = false;
-	bool aux_ok = !(getenv("ARX_AUX_STREAM") && atoi(getenv("ARX_AUX_STREAM")) == 0);
+	// Off by default: beside each other the launches shorten one batch alone (62.2 -> 59.5 ms) but cost 5-6 % of the throughput with three
+	// batches in flight (7.1 against 7.6 M pairs/s, same box): the other batches' kernels already fill the chip while a tail runs, and the
+	// cross-stream waits add bubbles.  ARX_AUX_STREAM=1 turns it on (latency-bound use: one batch at a time).
+	bool aux_ok = getenv("ARX_AUX_STREAM") && atoi(getenv("ARX_AUX_STREAM")) != 0;
 	template <class L> void on_aux(L f)
 	{
 		if (!aux_ok) { f(); return; }
