@@ -10,7 +10,9 @@
 //   * the order-dependent part of mem_sort_dedup_patch for one inserted region is settled from those masks exactly as dedup_insert()
 //     of dev_regs.h does it (who is met first on either side, where the reference's loop stops);
 //   * the shift that makes room for the region moves 64 records per step;
-//   * what is rare (a tie that needs the general pass, regions that go) is run by lane 0 with the serial code of dev_regs.h.
+//   * a tie with a listed region takes the general pass, also by the wavefront (w_sort_dedup: klib's introsort reproduced by w_introsort, the
+//     redundancy loop on bit masks); what is rarer still (regions that go on an insertion, lists beyond 256 regions) is run by lane 0 with
+//     the serial code of dev_regs.h.
 // Results are those of rescue_step() bit for bit (GPU tests on repeat-rich workloads, tests/test_config_shapes.py).
 #pragma once
 #include "dev_regs.h"
@@ -215,8 +217,8 @@ __device__ int w_squeeze(int n, Reg *a, Reg *tmp, const uint64_t keep[4])
 	return m;
 }
 
-// the sort of the general pass: w_introsort, or (ARX_WSORT_SERIAL, A/B builds) lane 0 running ks_introsort; ARX_WSORT_CHECK runs both and
-// flags a difference in ws.idx[W_SORT_MAX - 1] = -1 ... kept out of the product build
+// the sort of the general pass: w_introsort; ARX_WSORT_SERIAL (A/B builds): lane 0 running ks_introsort; ARX_WSORT_CHECK (test builds): both,
+// and a count of the sorts whose results differ (arx_cold.hip prints it after every launch) -- neither is part of the product build
 #if defined(ARX_WSORT_SERIAL)
 #define W_SORT(n, idx, lt, ws) do { if (threadIdx.x == 0) ks_introsort((n), (idx), (lt)); __syncthreads(); } while (0)
 #elif defined(ARX_WSORT_CHECK)
@@ -233,8 +235,8 @@ __device__ unsigned long long g_wsort_bad[2];
 // sort_dedup_patch() of dev_regs.h for n <= W_SORT_MAX, without patching: either because there is none (query == nullptr, the mate-rescue
 // call site: patch_l_pac < 0) or because no pair of regions gets past mem_patch_reg's geometric tests (patch_l_pac = l_pac; -2 is returned
 // if one does, before anything but the first sort has happened to the list in LDS).  The two
-// introsorts stay with lane 0 (their order of equal keys is part of the result) on an index array in LDS; everything around them is
-// spread over the lanes: for the redundancy pass every lane walks the earlier neighbours of its own regions and notes which are
+// introsorts are w_introsort on an index array in LDS (their order of equal keys is part of the result); the rest is spread over the
+// lanes as well: for the redundancy pass every lane walks the earlier neighbours of its own regions and notes which are
 // redundant with it (R) and which of those score higher (S) -- geometry only, independent of who has been dropped -- and the
 // reference's loop (bwamem.c:443-473) is then replayed on the masks: region i drops its alive redundant neighbours from the nearest
 // down, until one that scores higher drops i instead.
