@@ -11,9 +11,15 @@ import oradrv, parity, refdrv, rfadrv, workloads
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 bad = 0
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+mode = sys.argv[3] if len(sys.argv) > 3 else "mixed"   # "repeats": every seed a high-copy family (long region lists, ties): the wavefront-per-item kernels
 for seed in range(base, base + n_seeds):
     t = time.time()
-    if seed % 3 == 0:
+    if mode == "repeats":
+        r = np.random.default_rng(seed)
+        fams = [(int(r.integers(30, 220)), int(r.integers(800, 6000)), float(r.choice([0.0, 0.002, 0.01, 0.03]))), (int(r.integers(10, 60)), int(r.integers(200, 1500)), float(r.choice([0.0, 0.05])))]
+        g = synth.make_genome(seed, [int(r.integers(500_000, 2_500_000)), 50000], repeat_families=fams, n_runs=int(r.integers(0, 3)))
+        rs = synth.make_reads(seed + 1, g, 5, 240, molecule_len=int(r.integers(4000, 30000)), molecules_per_barcode=int(r.integers(3, 8)))
+    elif seed % 3 == 0:
         g = synth.make_genome(seed, [1500000, 400000]); rs = synth.make_reads(seed + 1, g, 6, 500)
     else:
         g = workloads.nasty_genome(seed, contig_lens=(180000 + 1000 * (seed % 7), 90000, 40000), alt_contigs=seed % 3)
