@@ -90,7 +90,18 @@ def _load(path):
     lib.arx_bam_error.argtypes = [vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
+    lib.arx_selftest_wave_sort.argtypes = [i32, i32, C.c_int64, vp]
     return lib
+
+
+def selftest_wave_sort(n_cases: int, seed: int = 1, device: int = 0, lib_path: str = LIB_PATH) -> int:
+    """klib's introsort as the wavefront kernels reproduce it against the one-thread original on random index arrays -> arrays that differ."""
+    lib = _load(lib_path)
+    bad = C.c_int64(-1)
+    rc = lib.arx_selftest_wave_sort(device, n_cases, seed, C.byref(bad))
+    if rc != 0:
+        raise ArachneError("arx_selftest_wave_sort: code %d" % rc)
+    return int(bad.value)
 
 
 def index_build(fasta: str, prefix: str, lib_path: str = LIB_PATH) -> None:

@@ -8,6 +8,7 @@ __shared__ unsigned long long lds_cstat[8];
 __device__ unsigned long long g_cstat[24];
 #define ARX_CHAIN_T(k) do { lds_cstat[k] = wall_clock64(); } while (0)
 #endif
+#include "../../include/arachne_amd.h"
 #include "hip_rt.h"
 #include "pipeline.h"
 #include "dev_regs_wave.h"
@@ -224,4 +225,55 @@ template <> struct ColdUsesSlots<KRescueStep> { static const bool value = false;
 template <class F> void HipRT::launch_cold(const char *nm, int n, const F &f) { launch_cold_impl(nm, n, f, !ColdUsesSlots<F>::value); }
 template void HipRT::launch_cold<KDedup>(const char *, int, const KDedup &);
 template void HipRT::launch_cold<KRescueStep>(const char *, int, const KRescueStep &);
+
+// ---- arx_selftest_wave_sort (include/arachne_amd.h): one random index array per workgroup, w_introsort against ks_introsort
+struct SelfKeyLt { const int *k; __device__ bool operator()(int a, int b) const { return k[a] < k[b]; } };
+static __global__ void __launch_bounds__(64) k_selftest_wsort(int n_cases, uint64_t seed, unsigned long long *n_bad)
+{
+	constexpr int MAXN = CHAIN_WAVE_MAX;
+	__shared__ int key[MAXN], idx[MAXN], chk[MAXN], lpos[MAXN], rpos[MAXN];
+	const int lane = threadIdx.x;
+	for (int c = blockIdx.x; c < n_cases; c += gridDim.x) {
+		uint64_t x = seed * 0x9E3779B97F4A7C15ull + (uint64_t)c * 0xD1B54A32D192ED03ull + 1;
+		auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+		const int n = 2 + (int)(next() % (uint64_t)(c % 4 == 0 ? MAXN - 1 : c % 4 == 1 ? 255 : c % 4 == 2 ? 40 : 15));
+		const int range = 1 + (int)(next() % (uint64_t)(c % 3 == 0 ? 4 : c % 3 == 1 ? n : 8 * n)); // few distinct keys ... hardly any ties
+		const int shape = (int)(next() % 4); // random, ascending, descending, ascending with a few swaps (the lists the passes sort are nearly sorted)
+		for (int i = lane; i < n; i += 64) {
+			uint64_t y = x + (uint64_t)i * 0x2545F4914F6CDD1Dull; y ^= y >> 29; y *= 0xBF58476D1CE4E5B9ull; y ^= y >> 32;
+			int k = (int)(y % (uint64_t)range);
+			if (shape == 1) k = (int)((int64_t)i * range / n);
+			else if (shape == 2) k = (int)((int64_t)(n - 1 - i) * range / n);
+			else if (shape == 3) k = (y >> 40) % 8 == 0 ? k : (int)((int64_t)i * range / n);
+			key[i] = k; idx[i] = i; chk[i] = i;
+		}
+		__syncthreads();
+		SelfKeyLt lt; lt.k = key;
+		if (lane == 0) ks_introsort(n, chk, lt);
+		__syncthreads();
+		if (n <= 256) w_introsort<256>(n, idx, lt, lpos, rpos);
+		else w_introsort<MAXN>(n, idx, lt, lpos, rpos);
+		bool bad = false;
+		for (int i = lane; i < n; i += 64) bad = bad || idx[i] != chk[i];
+		if (__ballot(bad) && lane == 0) atomicAdd(n_bad, 1ull);
+		__syncthreads();
+	}
+}
 } // namespace arx
+
+extern "C" int arx_selftest_wave_sort(int32_t device, int32_t n_cases, int64_t seed, int64_t *n_bad)
+{
+	if (n_cases < 0 || !n_bad) return ARX_E_ARG;
+	unsigned long long *d = nullptr, h = 0;
+	if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, 8) != hipSuccess) return ARX_E_DEVICE;
+	int rc = ARX_OK;
+	if (hipMemset(d, 0, 8) != hipSuccess) rc = ARX_E_DEVICE;
+	if (rc == ARX_OK && n_cases > 0) {
+		hipLaunchKernelGGL(arx::k_selftest_wsort, dim3(n_cases < 4096 ? n_cases : 4096), dim3(64), 0, 0, n_cases, (uint64_t)seed, d);
+		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = ARX_E_DEVICE;
+	}
+	if (rc == ARX_OK && hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = ARX_E_DEVICE;
+	(void)hipFree(d);
+	*n_bad = (int64_t)h;
+	return rc;
+}

@@ -179,6 +179,12 @@ int arx_batch_debug_intv(arx_ctx *ctx, arx_batch *b, int32_t *n_intv, uint64_t *
 int arx_batch_debug_chains(arx_ctx *ctx, arx_batch *b, int32_t *occ_off /* n_reads+1 */, int32_t *n_chain, arx_chain *chains, arx_seed *seeds /* counts[3] each */);
 int arx_batch_debug_core(arx_ctx *ctx, arx_batch *b, int32_t *n_core, arx_reg *regs /* counts[3] */);
 
+/* self-test of a device routine that has no host twin (tests): klib's introsort as a wavefront reproduces it (csrc/dev_regs_wave.h:
+ * w_introsort -- its order of equal keys is part of every result that passes mem_sort_dedup_patch or mem_chain_flt, ksort.h:176-226)
+ * against the one-thread ks_introsort, on n_cases random index arrays of 2..832 entries whose keys come from small ranges, so that ties
+ * abound.  *n_bad = arrays on which the two differ. */
+int arx_selftest_wave_sort(int32_t device, int32_t n_cases, int64_t seed, int64_t *n_bad);
+
 /* per-kernel device time (HIP events on the launch stream), accumulated since the last reset */
 int arx_kernel_times(arx_ctx *ctx, int32_t cap, char *names, int32_t name_w, double *ms, int64_t *calls, int64_t *items);
 void arx_kernel_times_reset(arx_ctx *ctx, int32_t enable);

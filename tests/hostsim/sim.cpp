@@ -217,3 +217,6 @@ extern "C" long arx_test_dedup_insert(unsigned seed, int iters, long *n_fast, lo
 	}
 	return cases;
 }
+
+// the wavefront routines exist on the GPU only (include/arachne_amd.h): nothing to test here
+extern "C" int arx_selftest_wave_sort(int32_t, int32_t, int64_t, int64_t *n_bad) { if (n_bad) *n_bad = 0; return ARX_E_DEVICE; }

@@ -170,3 +170,13 @@ def test_other_read_lengths_take_the_wide_kernel_variants(built, read_len):
     parity.check_rfa(b.rfa(po, [True] * 3), rfadrv.oracle_rfa(ora, rs.lens, po, [True] * 3, l_pac, offs))
     b.free()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_wave_introsort_equals_klib_introsort(built):
+    """The order klib's introsort leaves equal keys in is part of the reference's results (mem_sort_dedup_patch, mem_chain_flt).  The
+    wavefront-per-item kernels reproduce the algorithm with 64 lanes (dev_regs_wave.h: w_introsort); here against the one-thread
+    original on 20,000 random index arrays (2..832 entries; few, some or hardly any equal keys; random, sorted, reversed and nearly
+    sorted input)."""
+    assert api.selftest_wave_sort(20000, seed=20251004) == 0
+    assert api.selftest_wave_sort(20000, seed=7) == 0
