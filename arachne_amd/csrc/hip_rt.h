@@ -164,6 +164,9 @@ struct HipRT {
 	// seeding kernels: 4 * ARX_SEED_WPE resident blocks per CU (their register budget is compiled for that many waves per SIMD)
 	int seed_bpc = getenv("ARX_SEED_BPC") ? atoi(getenv("ARX_SEED_BPC")) : 4 * ARX_SEED_WPE;
 	int max_seed_slots() const { return n_cu * seed_bpc * 64; }
+	// the row-parallel backward kernel takes its grid a little larger than what is resident (16 per CU): the surplus workgroups start as the
+	// first ones run dry, which shortens the launch's tail (4.81 -> 4.62 ms alone at 20 per CU; 24 and more lose again)
+	int seed_bwd_bpc = getenv("ARX_SEED_BWD_BPC") ? atoi(getenv("ARX_SEED_BWD_BPC")) : 20;
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
 	void set_seed_read_len(int max_len) { seed_row = seed_row_bytes(max_len); }
 	// the batch's reads as nibble rows of seed_row bytes (hip_fm_coop.h: k_pack_reads): what the seeding kernels stage into LDS
@@ -383,7 +386,7 @@ struct HipRT {
 			int32_t *bins = alloc<int32_t>(3 * (size_t)n + 8), *cnt = alloc<int32_t>(8); // cnt[0..2]: bin sizes, cnt[4..6]: the three launches' item counters
 			memset0(flag, (size_t)n);
 			memset0(cnt, 32);
-			const int cap = n_cu * seed_bpc;
+			const int cap = n_cu * seed_bwd_bpc;
 			auto blocks_for = [&](int per_wave) { int b = (n + per_wave - 1) / per_wave; return b > cap ? cap : (b < 1 ? 1 : b); };
 			const size_t xch = 64 * 32;
 			{
