@@ -164,8 +164,8 @@ struct HipRT {
 	// seeding kernels: 4 * ARX_SEED_WPE resident blocks per CU (their register budget is compiled for that many waves per SIMD)
 	int seed_bpc = getenv("ARX_SEED_BPC") ? atoi(getenv("ARX_SEED_BPC")) : 4 * ARX_SEED_WPE;
 	int max_seed_slots() const { return n_cu * seed_bpc * 64; }
-	// the row-parallel backward kernel takes its grid a little larger than what is resident (16 per CU): the surplus workgroups start as the
-	// first ones run dry, which shortens the launch's tail (4.81 -> 4.62 ms alone at 20 per CU; 24 and more lose again)
+	// the row-parallel backward kernel needs 94 VGPRs: five wavefronts per SIMD fit, not only the four its launch bound asks for, so its grid is
+	// 20 workgroups per CU (4.81 -> 4.62 ms alone; 24 and more lose again, and a build that forces six per SIMD spills: 7.2 ms)
 	int seed_bwd_bpc = getenv("ARX_SEED_BWD_BPC") ? atoi(getenv("ARX_SEED_BWD_BPC")) : 20;
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
 	void set_seed_read_len(int max_len) { seed_row = seed_row_bytes(max_len); }
