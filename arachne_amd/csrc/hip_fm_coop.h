@@ -183,8 +183,7 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 		}
 		SeedTask k = SeedTask(); k.read = r; k.x = x; k.min_intv = 1; k.off = off; k.n = ln.n; k.nm = 0; k.next = -1;
 		A.P.tasks[t] = k;
-		Biv *dst = A.P.pool + off;
-		for (int e = 0; e < ln.n; ++e) dst[e] = list[ln.n - 1 - e]; // longest first (bwt.c:322)
+		// (the list itself was copied to pool + off by the wavefront, persistent_lanes())
 		if (last >= 0) A.P.tasks[last].next = t; else head = t;
 		last = t;
 		x = ln.ret();
@@ -219,9 +218,7 @@ struct FwdProg2 { // re-seeding: the forward extension of one task
 	{
 		awaiting = false; over = true;
 		if ((int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); return; } // n stays 0: the task is skipped
-		Biv *dst = A.P.pool + off;
-		for (int e = 0; e < ln.n; ++e) dst[e] = list[ln.n - 1 - e];
-		A.P.tasks[t].off = off; A.P.tasks[t].n = ln.n;
+		A.P.tasks[t].off = off; A.P.tasks[t].n = ln.n; // the list itself was copied to pool + off by the wavefront, persistent_lanes()
 	}
 	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
 	__device__ bool done() const { return over; }
@@ -366,6 +363,18 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 					}
 					base = __shfl(base, 0); tbase = __shfl(tbase, 0);
 					const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(askers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)askers, 0));
+					// The forward lists of the parked lanes go to their pool slices, longest first (bwt.c:322) -- one list after the other, every
+					// list by the whole wavefront (one coalesced trip per list).  A lane copying its own list waits for a round trip per entry,
+					// ~18 of them, with the rest of the wavefront waiting for it: that was most of what a refill cost.
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					for (unsigned long long m = askers; m; m &= m - 1) {
+						const int a = __builtin_ctzll(m);
+						const int n_a = __shfl(amt, a) / 3, off_a = __shfl(base + incl - amt, a);
+						if ((int64_t)off_a + 3 * n_a > A.P.pool_cap) continue; // granted() raises the error
+						const Biv *src = A.scratch + (size_t)(blockIdx.x * 64 + a) * A.list_cap;
+						for (int e = lane; e < n_a; e += 64) A.P.pool[off_a + e] = src[n_a - 1 - e];
+					}
 					if (amt > 0) {
 						prog.granted(base + incl - amt, tbase + rank);
 						have_req = prog.advance(&req, &rb, &rc, true); // on to the next start
