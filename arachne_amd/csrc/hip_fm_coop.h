@@ -363,18 +363,29 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 					}
 					base = __shfl(base, 0); tbase = __shfl(tbase, 0);
 					const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(askers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)askers, 0));
-					// The forward lists of the parked lanes go to their pool slices, longest first (bwt.c:322) -- one list after the other, every
-					// list by the whole wavefront (one coalesced trip per list).  A lane copying its own list waits for a round trip per entry,
-					// ~18 of them, with the rest of the wavefront waiting for it: that was most of what a refill cost.
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-					for (unsigned long long m = askers; m; m &= m - 1) {
-						const int a = __builtin_ctzll(m);
-						const int n_a = __shfl(amt, a) / 3, off_a = __shfl(base + incl - amt, a);
-						if ((int64_t)off_a + 3 * n_a > A.P.pool_cap) continue; // granted() raises the error
-						const Biv *src = A.scratch + (size_t)(blockIdx.x * 64 + a) * A.list_cap;
-						for (int e = lane; e < n_a; e += 64) A.P.pool[off_a + e] = src[n_a - 1 - e];
+					// The forward lists of the parked lanes go to their pool slices, longest first (bwt.c:322), copied by the whole wavefront: four
+					// lists per step, one per 16-lane quarter (most lists have 16 entries or fewer), their loads in flight together.  A lane copying
+					// its own list waits for a round trip per entry, ~18 of them, with the rest of the wavefront waiting for it: that was most of
+					// what a refill cost.
+					__shared__ int g_n[64], g_off[64], g_lane[64];
+					if (amt > 0) {
+						const int off = base + incl - amt;
+						g_n[rank] = (int64_t)off + amt <= A.P.pool_cap ? amt / 3 : 0; // 0: granted() raises the error, nothing is copied
+						g_off[rank] = off; g_lane[rank] = lane;
 					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					const int n_ask = __builtin_popcountll(askers), quarter = lane >> 4, el = lane & 15;
+					for (int k0 = 0; k0 < n_ask; k0 += 4) {
+						const int k = k0 + quarter;
+						if (k < n_ask) {
+							const int n_a = g_n[k], off_a = g_off[k];
+							const Biv *src = A.scratch + (size_t)(blockIdx.x * 64 + g_lane[k]) * A.list_cap;
+							for (int e = el; e < n_a; e += 16) A.P.pool[off_a + e] = src[n_a - 1 - e];
+						}
+					}
+					__builtin_amdgcn_wave_barrier(); // the LDS words are rewritten by the next refill
 					if (amt > 0) {
 						prog.granted(base + incl - amt, tbase + rank);
 						have_req = prog.advance(&req, &rb, &rc, true); // on to the next start
