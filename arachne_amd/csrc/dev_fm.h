@@ -244,28 +244,28 @@ struct SeedPools { // batch-wide, filled through atomic cursors; an overflow rai
 // forward half of bwt_smem1a (bwt.c:299-321) from position x (q[x] is a base): list[] receives the interval each time its
 // size changes, shortest match first
 template <class Q> struct FwdLane {
-	Q q; Biv *list; int len, i, min_intv, n; bool finished; Biv ik;
+	Q q; Biv *list; int len, i, min_intv, n, last_end; bool finished; Biv ik;
 	ARX_DEVI void start(const IndexView &ix, int len_, const Q &q_, int x, int min_intv_, Biv *list_)
 	{
-		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false;
+		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false; last_end = 0;
 		ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1;
 	}
 	ARX_DEVI bool advance(Biv *req, int *rc)
 	{
 		if (finished) return false;
-		if (i >= len || q.at(i) > 3) { list[n++] = ik; finished = true; return false; }
+		if (i >= len || q.at(i) > 3) { list[n++] = ik; last_end = (int)ik.info; finished = true; return false; }
 		*req = ik; *rc = 3 - q.at(i);
 		return true;
 	}
 	ARX_DEVI void consume(const Biv &ok)
 	{
 		if (ok.s != ik.s) {
-			list[n++] = ik;
+			list[n++] = ik; last_end = (int)ik.info;
 			if (ok.s < (uint64_t)min_intv) { finished = true; return; }
 		}
 		ik = ok; ik.info = i + 1; ++i;
 	}
-	ARX_DEVI int ret() const { return (int)list[n - 1].info; } // where the longest match ends: the next start of the first pass
+	ARX_DEVI int ret() const { return last_end; } // (int)list[n - 1].info, kept in a register: where the longest match ends = the next start of the first pass
 };
 
 // list[0..n) of a finished forward extension becomes a task: the pool slice gets it longest first (bwt.c:322)

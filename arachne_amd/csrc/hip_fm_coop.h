@@ -143,53 +143,63 @@ struct SeedKArgs { // shared by the three kernels
 // the driver serves all such lanes of the wave with ONE atomic per cursor (a per-lane atomic on the batch-wide cursors was the
 // bottleneck of the forward kernels) and calls granted().
 struct FwdProg1 { // first pass: the forward extensions of one read, start after start
+	// A finished forward list becomes a backward task once it has a pool slice, and slices are handed out in one step for the wavefront.
+	// The lane does not wait for that: the list stays where it is (`pending`, one of the lane's two list buffers) and the next extension
+	// starts at once in the other buffer -- where the next start lies is known from the list itself (bwt.c:356).  Only a lane that finishes
+	// a second list before the first one has its slice parks, and a few parked lanes are enough to trigger the hand-out (grant step of
+	// persistent_lanes()).  (Parking after every extension until 48 lanes had parked left 30 of 64 lanes extending.)
 	static constexpr bool ALLOCATES = true, NEW_TASK = true;
-	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last; bool extending, awaiting, over;
-	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), extending(false), awaiting(false), over(true) {}
+	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last, cur, pend_n, pend_x, pend_buf; bool extending, awaiting, over;
+	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), cur(0), pend_n(0), pend_x(0), pend_buf(0), extending(false), awaiting(false), over(true) {}
+	__device__ Biv *buf(int b) const { return list + b * (A.list_cap >> 1); }
 	__device__ bool begin(int item)
 	{
-		r = A.read0 + item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false;
+		r = A.read0 + item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false; pend_n = 0; cur = 0;
 		if (len > MAX_READ_LEN) { atomicOr(A.P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len < OPT_MIN_SEED_LEN) { A.first1[r] = -1; over = true; return false; }
 		return true;
 	}
-	__device__ bool advance(Biv *req, int *rb, int *rc, bool slow_ok)
+	__device__ void shelve() // the finished list of ln becomes the pending one; the next start is where its longest match ends
+	{
+		pend_n = ln.n; pend_x = x; pend_buf = cur; x = ln.ret(); cur ^= 1; extending = false;
+	}
+	__device__ bool advance(Biv *req, int *rb, int *rc, bool)
 	{
 		*rb = 0;
 		while (!over && !awaiting) {
 			if (extending) {
 				if (ln.advance(req, rc)) return true;
-				if (!slow_ok) return false;
-				awaiting = true; // the forward list becomes a backward task once its pool slice is granted
-				break;
+				if (pend_n > 0) { awaiting = true; break; } // two finished lists: wait for the slice of the first
+				shelve();
 			}
-			if (!slow_ok) return false;
 			while (x < len && q.at(x) > 3) ++x;
 			if (x >= len) { over = true; break; }
-			ln.start(A.ix, len, q, x, 1, list);
+			ln.start(A.ix, len, q, x, 1, buf(cur));
 			extending = true;
 		}
 		return false;
 	}
-	__device__ int want() const { return awaiting ? 3 * ln.n : 0; }
+	__device__ int want() const { return 3 * pend_n; }
+	__device__ bool parked() const { return awaiting; }
+	__device__ int export_off() const { return (int)(buf(pend_buf) - A.scratch); } // where the list to export lies, in entries from A.scratch
 	__device__ void granted(int off, int t)
 	{
-		awaiting = false; extending = false;
-		if (t >= A.P.task_cap || (int64_t)off + 3 * ln.n > A.P.pool_cap) {
+		const int n = pend_n;
+		pend_n = 0;
+		if (t >= A.P.task_cap || (int64_t)off + 3 * n > A.P.pool_cap) {
 			atomicOr(A.P.err, ERR_POOL_OVERFLOW);
 			if (t < A.P.task_cap) { SeedTask e = SeedTask(); e.read = r; e.next = -1; A.P.tasks[t] = e; } // the id is taken: leave an empty task the later kernels skip
-			over = true;
+			over = true; awaiting = false;
 			return;
 		}
-		SeedTask k = SeedTask(); k.read = r; k.x = x; k.min_intv = 1; k.off = off; k.n = ln.n; k.nm = 0; k.next = -1;
-		A.P.tasks[t] = k;
-		// (the list itself was copied to pool + off by the wavefront, persistent_lanes())
+		SeedTask k = SeedTask(); k.read = r; k.x = pend_x; k.min_intv = 1; k.off = off; k.n = n; k.nm = 0; k.next = -1;
+		A.P.tasks[t] = k; // (the list itself was copied to pool + off by the wavefront, persistent_lanes())
 		if (last >= 0) A.P.tasks[last].next = t; else head = t;
 		last = t;
-		x = ln.ret();
+		if (awaiting) { awaiting = false; shelve(); } // the parked second list moves up
 	}
 	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
-	__device__ bool done() const { return over; }
+	__device__ bool done() const { return over && pend_n == 0; }
 	__device__ void finish() { A.first1[r] = head; }
 };
 
@@ -210,10 +220,13 @@ struct FwdProg2 { // re-seeding: the forward extension of one task
 		*rb = 0;
 		if (over || awaiting) return false;
 		if (ln.advance(req, rc)) return true;
-		if (slow_ok) awaiting = true;
+		(void)slow_ok;
+		awaiting = true; // the list wants its pool slice: handed out in the wavefront's next grant step
 		return false;
 	}
 	__device__ int want() const { return awaiting ? 3 * ln.n : 0; }
+	__device__ bool parked() const { return awaiting; }
+	__device__ int export_off() const { return (int)(list - A.scratch); }
 	__device__ void granted(int off, int)
 	{
 		awaiting = false; over = true;
@@ -245,6 +258,8 @@ struct BwdProg { // the backward sweep of one task
 	}
 	__device__ bool advance(Biv *req, int *rb, int *rc, bool) { *rb = 1; return ln.advance(req, rc, A.budget); }
 	__device__ int want() const { return 0; }
+	__device__ bool parked() const { return false; }
+	__device__ int export_off() const { return 0; }
 	__device__ void granted(int, int) {}
 	__device__ void consume(const Biv &req, const Biv &ok) { ln.consume(req, ok); }
 	__device__ bool done() const { return ln.finished; }
@@ -328,9 +343,9 @@ static __global__ void __launch_bounds__(64) k_seed_bwd_wave(SeedKArgs A)
 }
 
 template <class Prog, bool BY_TASK>
-__device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int32_t *counter, int batch, int chunk, uint8_t *q_lds)
+__device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int32_t *counter, int batch_grant, int chunk, uint8_t *q_lds)
 {
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x, batch = batch_grant & 0xff, grant = (batch_grant >> 8) > 0 ? batch_grant >> 8 : 64; // (hip_rt.h packs the two thresholds)
 	Prog prog(A, A.scratch + (size_t)(blockIdx.x * 64 + lane) * A.list_cap, QNibbles{q_lds + lane * A.row});
 	ItemFeeder feed;
 	int item = -1; // what this lane is working on, -1 = idle
@@ -342,56 +357,58 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 		if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, false); // cheap part: the next request of a running extension
 		const int waiting = __builtin_popcountll(__ballot(!have_req));
 		if (A.dbg) { ++n_it; n_ext += 64 - waiting; }
-		if (waiting >= batch || waiting == 64) {
+		// two steps off the extension loop, each for many lanes at once: the GRANT step hands pool slices (and task ids) to the lanes with a
+		// finished list -- cheap: two atomics and the copies -- as soon as `grant` lanes are parked for one; the REFILL step (finish reads,
+		// deal new ones, stage their rows) waits for `batch` lanes without work
+		const bool refill = waiting >= batch || waiting == 64;
+		const bool grants = Prog::ALLOCATES && (refill || __builtin_popcountll(__ballot(item >= 0 && prog.parked())) >= grant);
+		if (grants) { // pool slices (and task ids) for every lane that has a finished list: one atomic per cursor and wave
+			const int amt = item >= 0 ? prog.want() : 0;
+			const unsigned long long askers = __ballot(amt > 0);
+			if (askers) {
+				int incl = amt;
+				for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+				const int total = __shfl(incl, 63);
+				int base = 0, tbase = 0;
+				if (lane == 0) {
+					base = atomicAdd(A.P.cursors, total);
+					if (Prog::NEW_TASK) tbase = atomicAdd(A.P.cursors + 1, __builtin_popcountll(askers));
+				}
+				base = __shfl(base, 0); tbase = __shfl(tbase, 0);
+				const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(askers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)askers, 0));
+				// The finished forward lists go to their pool slices, longest first (bwt.c:322), copied by the whole wavefront: four lists per
+				// step, one per 16-lane quarter (most lists have 16 entries or fewer), their loads in flight together.  A lane copying its own
+				// list waits for a round trip per entry, ~18 of them, with the rest of the wavefront waiting for it.
+				__shared__ int g_n[64], g_off[64], g_src[64];
+				if (amt > 0) {
+					const int off = base + incl - amt;
+					g_n[rank] = (int64_t)off + amt <= A.P.pool_cap ? amt / 3 : 0; // 0: granted() raises the error, nothing is copied
+					g_off[rank] = off; g_src[rank] = prog.export_off();
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const int n_ask = __builtin_popcountll(askers), quarter = lane >> 4, el = lane & 15;
+				for (int k0 = 0; k0 < n_ask; k0 += 4) {
+					const int k = k0 + quarter;
+					if (k < n_ask) {
+						const int n_a = g_n[k], off_a = g_off[k];
+						const Biv *src = A.scratch + g_src[k];
+						for (int e = el; e < n_a; e += 16) A.P.pool[off_a + e] = src[n_a - 1 - e];
+					}
+				}
+				__builtin_amdgcn_wave_barrier(); // the LDS words are rewritten by the next grant step
+				if (amt > 0) prog.granted(base + incl - amt, tbase + rank);
+			}
+			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // a lane whose parked list just got its slice goes on
+		}
+		if (refill) {
 			++n_slow;
 			if (item >= 0 && !have_req && prog.done()) { prog.finish(); item = -1; }
 			bool took;
 			if (!feed.deal(item, took, BY_TASK ? A.P.tasks : nullptr, A.t0, A.qn, n, counter, chunk, q_lds, A.row, A.read0)) break;
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
-			if (Prog::ALLOCATES) { // pool slices (and task ids) for every lane that parked for them: one atomic per cursor and wave
-				const int amt = (item >= 0 && !have_req) ? prog.want() : 0;
-				const unsigned long long askers = __ballot(amt > 0);
-				if (askers) {
-					int incl = amt;
-					for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-					const int total = __shfl(incl, 63);
-					int base = 0, tbase = 0;
-					if (lane == 0) {
-						base = atomicAdd(A.P.cursors, total);
-						if (Prog::NEW_TASK) tbase = atomicAdd(A.P.cursors + 1, __builtin_popcountll(askers));
-					}
-					base = __shfl(base, 0); tbase = __shfl(tbase, 0);
-					const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(askers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)askers, 0));
-					// The forward lists of the parked lanes go to their pool slices, longest first (bwt.c:322), copied by the whole wavefront: four
-					// lists per step, one per 16-lane quarter (most lists have 16 entries or fewer), their loads in flight together.  A lane copying
-					// its own list waits for a round trip per entry, ~18 of them, with the rest of the wavefront waiting for it: that was most of
-					// what a refill cost.
-					__shared__ int g_n[64], g_off[64], g_lane[64];
-					if (amt > 0) {
-						const int off = base + incl - amt;
-						g_n[rank] = (int64_t)off + amt <= A.P.pool_cap ? amt / 3 : 0; // 0: granted() raises the error, nothing is copied
-						g_off[rank] = off; g_lane[rank] = lane;
-					}
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					__builtin_amdgcn_wave_barrier();
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-					const int n_ask = __builtin_popcountll(askers), quarter = lane >> 4, el = lane & 15;
-					for (int k0 = 0; k0 < n_ask; k0 += 4) {
-						const int k = k0 + quarter;
-						if (k < n_ask) {
-							const int n_a = g_n[k], off_a = g_off[k];
-							const Biv *src = A.scratch + (size_t)(blockIdx.x * 64 + g_lane[k]) * A.list_cap;
-							for (int e = el; e < n_a; e += 16) A.P.pool[off_a + e] = src[n_a - 1 - e];
-						}
-					}
-					__builtin_amdgcn_wave_barrier(); // the LDS words are rewritten by the next refill
-					if (amt > 0) {
-						prog.granted(base + incl - amt, tbase + rank);
-						have_req = prog.advance(&req, &rb, &rc, true); // on to the next start
-					}
-				}
-			}
 		}
 		if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}

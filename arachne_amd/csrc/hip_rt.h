@@ -329,6 +329,7 @@ struct HipRT {
 	// k_seed_bwd2 (51-61 of 64 lanes extending instead of 25-32, but no faster: profiles/r02/README.md).  0 = round 1's k_seed_bwd.
 	// All three are bit-identical.
 	int seed_bwd2 = getenv("ARX_SEED_BWD2") ? atoi(getenv("ARX_SEED_BWD2")) : 2;
+	int seed_grant = getenv("ARX_SEED_GRANT") ? atoi(getenv("ARX_SEED_GRANT")) : 4; // forward kernels: lanes parked for a pool slice that trigger the hand-out
 	int seed_bwd_batch = getenv("ARX_SEED_BWD_BATCH") ? atoi(getenv("ARX_SEED_BWD_BATCH")) : 0; // 0: seed_batch
 	// diagnostics (ARX_SEED_STATS=1): lane utilisation of the persistent-lane seeding kernels, printed per launch
 	unsigned long long *seed_dbg_buf = nullptr;
@@ -354,7 +355,7 @@ struct HipRT {
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
 		int blocks = (n + 63) / 64; if (blocks > n_cu * bpc_) blocks = n_cu * bpc_;
-		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, batch_, chunk_);
+		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, (batch_ & 0xff) | seed_grant << 8, chunk_);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *counter)

@@ -509,13 +509,13 @@ public:
 	// ---- stage 1+2: seeding and locate.  Leaves intervals and located seeds on the device.
 	int stage_seed(const DeviceBatch &b, Work &w)
 	{
-		const int R = b.n_reads, slots = rt.max_seed_slots() > rt.max_slots() ? rt.max_seed_slots() : rt.max_slots(), list_cap = b.max_len + 2;
+		const int R = b.n_reads, slots = rt.max_seed_slots() > rt.max_slots() ? rt.max_seed_slots() : rt.max_slots(), list_cap = 2 * (b.max_len + 2); // two forward lists per resident lane (hip_fm_coop.h: FwdProg1)
 		rt.set_seed_read_len(b.max_len);
 		rt.seed_prepare(b.bases, b.base_off, b.lens, R);
 		w.err = rt.template alloc<uint32_t>(4); rt.memset0(w.err, 16);
 		w.counter = rt.template alloc<int32_t>(4);
 		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);
-		w.smem_scr = rt.template alloc<Biv>((size_t)slots * list_cap); // one forward list per resident lane
+		w.smem_scr = rt.template alloc<Biv>((size_t)slots * list_cap);
 		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
 		Biv *strat = rt.template alloc<Biv>((size_t)R * CAP_STRAT);
 		int32_t *n_strat = rt.template alloc<int32_t>(R + 1);
