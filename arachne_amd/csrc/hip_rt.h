@@ -329,7 +329,7 @@ struct HipRT {
 	// k_seed_bwd2 (51-61 of 64 lanes extending instead of 25-32, but no faster: profiles/r02/README.md).  0 = round 1's k_seed_bwd.
 	// All three are bit-identical.
 	int seed_bwd2 = getenv("ARX_SEED_BWD2") ? atoi(getenv("ARX_SEED_BWD2")) : 2;
-	int seed_grant = getenv("ARX_SEED_GRANT") ? atoi(getenv("ARX_SEED_GRANT")) : 4; // forward kernels: lanes parked for a pool slice that trigger the hand-out
+	int seed_grant = getenv("ARX_SEED_GRANT") ? atoi(getenv("ARX_SEED_GRANT")) : 4; // first forward pass: lanes parked for a pool slice that trigger the hand-out (5.36 ms with none, 5.17 at 16, 4.94 at 4, 5.08 at 1)
 	int seed_bwd_batch = getenv("ARX_SEED_BWD_BATCH") ? atoi(getenv("ARX_SEED_BWD_BATCH")) : 0; // 0: seed_batch
 	// diagnostics (ARX_SEED_STATS=1): lane utilisation of the persistent-lane seeding kernels, printed per launch
 	unsigned long long *seed_dbg_buf = nullptr;
@@ -348,14 +348,14 @@ struct HipRT {
 		fprintf(stderr, "[arx seed stats] %s: %d items, %llu waves, %.0f iterations/wave, %.1f lanes extending per iteration, %.0f slow-path entries/wave\n", nm, n, h[3],
 		        h[3] ? (double)h[0] / h[3] : 0.0, h[0] ? (double)h[1] / h[0] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0);
 	}
-	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_, int chunk_ = 0, int batch_ = 0)
+	template <class K> void launch_seed_kernel(const char *nm, K kern, int n, const SeedKArgs &A, int32_t *counter, int bpc_, int chunk_ = 0, int batch_ = 0, int grant_ = 64)
 	{
 		if (chunk_ <= 0) chunk_ = seed_chunk;
 		if (batch_ <= 0) batch_ = seed_batch;
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
 		int blocks = (n + 63) / 64; if (blocks > n_cu * bpc_) blocks = n_cu * bpc_;
-		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, (batch_ & 0xff) | seed_grant << 8, chunk_);
+		hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 64 * (size_t)seed_row, stream, A, n, counter, (batch_ & 0xff) | grant_ << 8, chunk_);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
 	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *counter)
@@ -363,7 +363,7 @@ struct HipRT {
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
 		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, f.scratch, f.list_cap, f.first1, 0, nullptr, nullptr, 0, seed_row, seed_qn, f.read0, seed_dbg()};
-		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, seed_bpc);
+		launch_seed_kernel(nm, k_seed_fwd1, n, A, counter, seed_bpc, 0, 0, seed_grant); // (the re-seeding pass has one extension per item: no grant step of its own)
 		seed_dbg_report(nm, n);
 	}
 	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *counter)
