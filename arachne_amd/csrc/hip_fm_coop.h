@@ -585,12 +585,18 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 		__builtin_amdgcn_sched_barrier(0);
 		ExtLoad L;
 		ext_issue(A.ix, ent, 1, ext, L);
-		const SeedTask kt2 = A.P.tasks[stage == 1 ? t : A.t0];
-		const Biv e0 = A.P.pool[(stage == 2 && gl < k.n) ? k.off + gl : 0];       // the forward list, longest match first (bwt.c:322)
-		const uint32_t *src = A.qn + (size_t)(stage == 2 ? k.read : 0) * rw;
+		SeedTask kt2 = SeedTask();
+		Biv e0 = Biv();
 		uint32_t wv[NW];
 #pragma unroll
-		for (int u = 0; u < NW; ++u) wv[u] = src[gl + GL * u < rw ? gl + GL * u : 0];
+		for (int u = 0; u < NW; ++u) wv[u] = 0;
+		if (__ballot(stage == 1 || stage == 2)) { // (wave-uniform) some group is taking a task: its loads ride along with the Occ loads of the others
+			kt2 = A.P.tasks[stage == 1 ? t : A.t0];
+			e0 = A.P.pool[(stage == 2 && gl < k.n) ? k.off + gl : 0];       // the forward list, longest match first (bwt.c:322)
+			const uint32_t *src = A.qn + (size_t)(stage == 2 ? k.read : 0) * rw;
+#pragma unroll
+			for (int u = 0; u < NW; ++u) wv[u] = src[gl + GL * u < rw ? gl + GL * u : 0];
+		}
 		__builtin_amdgcn_sched_barrier(0);
 		// D. (the first use waits)  E. consume
 		Biv ok = Biv();
