@@ -178,11 +178,11 @@ struct KOccRid {
 	ARX_DEV void operator()(int g, int) const { const Seed s = occ_seed[g]; occ_rid[g] = intv2rid(ix, s.rbeg, s.rbeg + s.len); }
 };
 
-// Reads with many seed occurrences (reads in high-copy repeats: 0.1 % of a GRCh38-size batch carries 33-800 of them, against a median
+// Reads with many seed occurrences (reads in high-copy repeats: 0.1 % of a GRCh38-size batch carries 65-800 of them, against a median
 // of 8) are 85 % of the thread-per-read kernel's time -- one lane walking a B-tree and chain lists in HBM, several thousand dependent
 // round trips -- while the other 99.9 % finish in a quarter of it.  KChain hands such a read to k_chain_heavy (arx_cold.hip): one
 // wavefront per read, the read's working set in LDS.
-constexpr int CHAIN_HEAVY_MIN = 32, CHAIN_LDS_OCC = 832; // 832 occurrences x 154 B of working set = 128 KB of a CU's 160 KB LDS
+constexpr int CHAIN_HEAVY_MIN = 64, CHAIN_LDS_OCC = 832; // 832 occurrences x 154 B of working set = 128 KB of a CU's 160 KB LDS
 struct KChain {
 	IndexView ix; const int32_t *lens; const Biv *intv; const int32_t *n_intv, *occ_off; const Seed *occ_seed; const int32_t *occ_rid;
 	int32_t *next; Chain *ctmp; BtNode *nodes; int32_t *iscr; Chain *cout; Seed *sout; int32_t *n_chain; uint32_t *err;
@@ -307,7 +307,7 @@ struct KPairCap {
 // LDS (hip_rt.h: k_rescue_heavy): the replay is one thread walking and shifting 88-byte records, a chain of dependent memory round trips
 // that costs 10-14 ms per round from HBM / L2 and a fraction of that from LDS.  heavy[p] marks such a pair (both lists with their spare
 // capacity must fit RESCUE_LDS_REGS records); the thread-per-pair kernel skips them.
-constexpr int RESCUE_HEAVY_MIN = 24, RESCUE_LDS_REGS = 680; // 680 x 88 B = 58.4 KB; with the 17 KB of the wave's sort scratch two workgroups share a CU's 160 KB
+constexpr int RESCUE_HEAVY_MIN = 48, RESCUE_LDS_REGS = 680; // 680 x 88 B = 58.4 KB; with the 17 KB of the wave's sort scratch two workgroups share a CU's 160 KB
 struct KPairInit {
 	const int32_t *occ_off, *n_core, *preg_off; const Reg *regs; Reg *pregs; int32_t *n_regs; ResState *state; const int32_t *core_clean;
 	const int32_t *cap; uint8_t *heavy; int32_t *heavy_list, *n_heavy; // null: no heavy path

@@ -103,15 +103,15 @@ def test_segdup_reads_gpu(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("heavy_min", ["6", "24"])
+@pytest.mark.parametrize("heavy_min", ["6", "48"])
 def test_long_lists_with_exact_ties_wave_rescue_gpu(built, monkeypatch, heavy_min):
     """Pairs whose region lists are long AND full of exact ties (80 identical 3 kb copies next to a 50-copy family at 0.3 %): the rescue
     replay of such pairs runs in the one-wavefront-per-pair kernel (dev_regs_wave.h), ties send it through its general pass; their
     chaining (65+ seed occurrences per read, dozens of chains of equal weight) runs in the one-wavefront-per-read kernel
     (dev_chain_wave.h).  With the thresholds lowered (6 regions, 4 occurrences) nearly every pair / read of the batch takes those
-    kernels; 24 / 32 are the product settings."""
+    kernels; 48 / 64 are the product settings."""
     monkeypatch.setenv("ARX_RESCUE_HEAVY_MIN", heavy_min)
-    monkeypatch.setenv("ARX_CHAIN_HEAVY_MIN", "4" if heavy_min == "6" else "32")       # likewise the one-wavefront-per-read chaining kernel
+    monkeypatch.setenv("ARX_CHAIN_HEAVY_MIN", "4" if heavy_min == "6" else "64")       # likewise the one-wavefront-per-read chaining kernel
     monkeypatch.setenv("ARX_DEDUP_HEAVY_MIN", "2" if heavy_min == "6" else "32")       # and the one that de-duplicates a read's regions
     g = synth.make_genome(75, [2_000_000, 30000], repeat_families=[(80, 3000, 0.0), (50, 2000, 0.003)], n_runs=1)
     rs = synth.make_reads(76, g, 6, 150, molecule_len=10000, molecules_per_barcode=5)
