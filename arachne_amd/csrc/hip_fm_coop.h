@@ -538,6 +538,7 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 	Biv *xch = (Biv *)(lds_g16 + ((NG * A.row + 31) & ~31)) + g * GL;
 	const QNibbles q{q_row};
 	const unsigned long long gmask = GL == 64 ? ~0ull : ((1ull << (GL & 63)) - 1) << (GL * g);
+	const unsigned long long lowmask = gmask & ((1ull << lane) - 1); // the lanes of this group below this one
 	int stage = 0, t = -1;                                    // group-uniform: 0 idle, 1 task id taken, 2 task loaded, 3 running
 	SeedTask k = SeedTask();
 	Biv ent = Biv();                                          // this lane's entry of the current row (valid: gl < n_prev)
@@ -602,21 +603,22 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 		Biv ok = Biv();
 		if (ext) ok = ext_finish(A.ix, ent, 1, c, L);
 		const bool keep = ext && ok.s >= (uint64_t)k.min_intv;
-		const unsigned long long km = (__ballot(keep) & gmask) >> (GL * g), fm = (__ballot(ext && !keep) & gmask) >> (GL * g);
-		const unsigned long long lower = (1ull << gl) - 1, below = km & lower;
-		const int p = below ? 63 - __builtin_clzll(below) : 0;
-		const uint64_t ps = shfl_u64(ok.s, GL * g + p);
+		// ballots stay wave-wide; this group's part is cut out with masks that do not change (no shifts by the group's position)
+		const unsigned long long km = __ballot(keep) & gmask, fm = __ballot(ext && !keep) & gmask;
+		const unsigned long long below = km & lowmask;
+		const int p = below ? 63 - __builtin_clzll(below) : 0; // lane of the nearest survivor below this one
+		const uint64_t ps = shfl_u64(ok.s, p);
 		const bool push = keep && (!below || ok.s != ps);
-		const unsigned long long pm = (__ballot(push) & gmask) >> (GL * g);
+		const unsigned long long pm = __ballot(push) & gmask;
 		if (stage == 3) {
 			if (fm) { // the first interval that died, if no survivor precedes it in the row
 				const int jf = __builtin_ctzll(fm);
 				if ((km & ((1ull << jf) - 1)) == 0 && (nm == 0 || i + 1 < mls)) {
-					if (gl == jf) { Biv x = ent; x.info |= (uint64_t)(i + 1) << 32; A.P.pool[k.off + 2 * k.n + nm] = x; }
+					if (lane == jf) { Biv x = ent; x.info |= (uint64_t)(i + 1) << 32; A.P.pool[k.off + 2 * k.n + nm] = x; }
 					++nm; mls = i + 1;
 				}
 			}
-			if (push) { Biv x = ok; x.info = ent.info; xch[__builtin_popcountll(pm & lower)] = x; }
+			if (push) { Biv x = ok; x.info = ent.info; xch[__builtin_popcountll(pm & lowmask)] = x; }
 		}
 		if (stage == 2) { // the read row of the group and its first list
 			uint32_t *dst = (uint32_t *)q_row;
