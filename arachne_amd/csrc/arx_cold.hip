@@ -163,8 +163,8 @@ template <> void HipRT::run_chain_heavy<KChain>(const char *nm, int n_reads, con
 	Scope sc(*this, nm, n_reads);
 	static const int wave = getenv("ARX_CHAIN_WAVE") ? atoi(getenv("ARX_CHAIN_WAVE")) : 1;
 	static const size_t lds_s = ChainLds::bytes(CHAIN_LDS_SMALL), lds_l = ChainLds::bytes(CHAIN_LDS_OCC);
-	static bool attr_set = false;
-	if (!attr_set) { ARX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
+	// the opt-in applies to the device that is current when it is made: once per runtime (= per device context), not once per process
+	if (!chain_heavy_attr_set) { ARX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); chain_heavy_attr_set = true; }
 	// f.n_heavy[0]: the list's length (stays on the device), [1] and [2]: the two launches' cursors into it
 	static const int l_div = getenv("ARX_CHAIN_L_DIV") ? atoi(getenv("ARX_CHAIN_L_DIV")) : 1; // the long ones' launch holds 128 KB of LDS per workgroup: on n_cu / l_div CUs
 	on_aux([&]() { hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu / (l_div > 0 ? l_div : 1)), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); }); // the few long ones (beside the rest with ARX_AUX_STREAM=1)
@@ -223,6 +223,7 @@ template <> void HipRT::run_dedup_heavy<KDedup>(const char *nm, int n_reads, con
 template <class F> struct ColdUsesSlots { static const bool value = true; };
 template <> struct ColdUsesSlots<KRescueStep> { static const bool value = false; }; // no per-slot scratch: may take one item per lane
 template <class F> void HipRT::launch_cold(const char *nm, int n, const F &f) { launch_cold_impl(nm, n, f, !ColdUsesSlots<F>::value); }
+void HipRT::merge_sort_fail_cold(uint32_t *err) { hipLaunchKernelGGL(k_merge_sort_fail, dim3(1), dim3(1), 0, stream, err); } // this unit's copy of the flag
 template void HipRT::launch_cold<KDedup>(const char *, int, const KDedup &);
 template void HipRT::launch_cold<KRescueStep>(const char *, int, const KRescueStep &);
 

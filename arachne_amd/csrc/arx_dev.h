@@ -164,6 +164,15 @@ ARX_DEVI int cal_max_gap(int qlen)
 #ifndef ARX_SORT_ATTR_COMB
 #define ARX_SORT_ATTR_COMB ARX_SORT_ATTR
 #endif
+// set when ks_introsort's iteration budget runs out (it cannot: see below); one word per translation unit of the device code
+#if defined(__HIPCC__)
+static __device__ unsigned int g_arx_sort_fail;
+#define ARX_SORT_FAIL() atomicOr(&g_arx_sort_fail, 1u)
+static __global__ void k_merge_sort_fail(uint32_t *err) { if (g_arx_sort_fail) atomicOr(err, (uint32_t)ERR_INTERNAL); }
+#else
+static unsigned int g_arx_sort_fail; // host test double
+#define ARX_SORT_FAIL() (g_arx_sort_fail = 1u)
+#endif
 template <class LT> ARX_DEV ARX_SORT_ATTR_INS void ks_insertsort(int *s, int *t, LT lt)
 {
 	for (int *i = s + 1; i < t; ++i)
@@ -206,7 +215,10 @@ template <class LT> ARX_DEV ARX_SORT_ATTR void ks_introsort(int n, int *a, LT lt
 	s = a; t = a + (n - 1); d <<= 1;
 	bool done = false;
 	long budget = 4L * (n + 8) * (n + 8); // never reached (see above)
-#define ARX_GUARD() if (--budget < 0) return;
+	// ... and if it ever were, nothing stays silent: the flag below ends up in the error word of every batch that finishes afterwards
+	// (HipRT::merge_sort_fail -> ERR_INTERNAL), and the range is left fully sorted by the insertion sort (whose order of equal keys
+	// need not be klib's: hence the error)
+#define ARX_GUARD() if (--budget < 0) { ARX_SORT_FAIL(); ks_insertsort(a, a + n, lt); return; }
 	while (!done) {
 		ARX_GUARD()
 		if (s < t) {

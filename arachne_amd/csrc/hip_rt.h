@@ -243,12 +243,16 @@ struct HipRT {
 	// "cold" kernels (list bookkeeping: dedup, rescue_step) are instantiated in arx_cold.hip, a translation unit of its own (-O3 like
 	// the rest since round 2; arx_dev.h ks_introsort has the story of the -O1 build they needed before)
 	template <class F> void launch_cold(const char *nm, int n, const F &f);
+	// ks_introsort's budget flag (arx_dev.h) of both device translation units into a batch's error word; no host round trip of its own
+	void merge_sort_fail(uint32_t *err) { hipLaunchKernelGGL(k_merge_sort_fail, dim3(1), dim3(1), 0, stream, err); merge_sort_fail_cold(err); }
+	void merge_sort_fail_cold(uint32_t *err); // arx_cold.hip
 	// rescue replay of the pairs with long lists, lists staged in LDS (arx_cold.hip)
 	bool rescue_heavy_ok() const { return !(getenv("ARX_RESCUE_HEAVY") && atoi(getenv("ARX_RESCUE_HEAVY")) == 0); }
 	template <class F> void run_rescue_heavy(const char *nm, int n, const int32_t *list, const F &f);
 	// chaining of the reads with many seed occurrences, one wavefront per read on a working set in LDS (arx_cold.hip); f.heavy_list / f.n_heavy
 	bool chain_heavy_ok() const { return !(getenv("ARX_CHAIN_HEAVY") && atoi(getenv("ARX_CHAIN_HEAVY")) == 0); }
 	template <class F> void run_chain_heavy(const char *nm, int n_reads, const F &f);
+	bool chain_heavy_attr_set = false; // the 128 KB dynamic-LDS opt-in of k_chain_heavy was made on this runtime's device
 	bool dedup_heavy_ok() const { return !(getenv("ARX_DEDUP_HEAVY") && atoi(getenv("ARX_DEDUP_HEAVY")) == 0); }
 	template <class F> void run_dedup_heavy(const char *nm, int n_reads, const F &f); // likewise the region lists of such reads (f.eh_words ints of scratch per workgroup)
 	template <class F> void launch_cold_impl(const char *nm, int n, const F &f, bool wide = false)

@@ -704,6 +704,7 @@ public:
 			}
 			k.mode = 2;
 			rt.launch_small("reg2aln_nw_big", n2[1], k);
+			rt.merge_sort_fail(w.err);
 			uint32_t e = read_err(w);
 			if (!(e & ERR_CIGAR_OVERFLOW)) { compact(b, w); return (int)e; }
 			if (w.cig_w >= 1024) return (int)e;

@@ -144,11 +144,12 @@ def merge_in_read_set_order(per_rank, assign, pair_off):
     cand_off = np.zeros(n_reads + 1, dtype=np.int64)
     regs, alns, cigs, cands = [], [], [], []
     n_reg = n_cig = n_cand = 0
+    off64 = [(S["reg_off"].astype(np.int64), S["cand_off"].astype(np.int64)) for S in per_rank]   # once per rank, not per barcode
     for b in range(n_bc):
         r, lr0 = where[b]
         S = per_rank[r]
         g0, nr = 2 * int(pair_off[b]), 2 * int(pair_off[b + 1] - pair_off[b])
-        ro, co = S["reg_off"].astype(np.int64), S["cand_off"].astype(np.int64)
+        ro, co = off64[r]
         r0, r1 = int(ro[lr0]), int(ro[lr0 + nr])
         c0, c1 = int(co[lr0]), int(co[lr0 + nr])
         reg_off[g0:g0 + nr] = ro[lr0:lr0 + nr] - r0 + n_reg
@@ -164,6 +165,8 @@ def merge_in_read_set_order(per_rank, assign, pair_off):
         regs.append(S["regs"][r0:r1]); alns.append(a); cigs.append(S["cigars"][w0:w1]); cands.append(cd)
         n_reg += r1 - r0; n_cig += w1 - w0; n_cand += c1 - c0
     reg_off[n_reads], cand_off[n_reads] = n_reg, n_cand
+    if max(n_reg, n_cig, n_cand) >= 1 << 31:
+        raise ValueError("the gathered set holds %d regions / %d CIGAR words / %d candidates: beyond the 32-bit offsets of one result slab -- gather fewer barcodes per step" % (n_reg, n_cig, n_cand))
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
     return dict(reg_off=reg_off.astype(np.int32), regs=cat(regs, api.REG_DTYPE), alns=cat(alns, api.ALN_DTYPE), cigars=cat(cigs, np.uint32),
                 cand_off=cand_off.astype(np.int32), cands=cat(cands, api.CAND_DTYPE))

@@ -20,6 +20,8 @@ class Genome:
     names: list          # contig names
     seqs: list           # list of uint8 arrays (0..4)
     alt: list            # bool per contig (goes to the .alt file)
+    copies: np.ndarray = None   # (n, 4) int64 rows [family, contig, position, length]: where make_genome planted its repeat copies
+    fam_weight: np.ndarray = None  # per family: share of the repeat-biased molecules make_reads draws from it
 
     @property
     def total_len(self) -> int:
@@ -56,11 +58,24 @@ def _mutate(rng, s, div):
     return s
 
 
-def make_genome(seed: int, contig_lens, repeat_families=None, n_runs: int = 2, alt_contigs: int = 0, fast: bool = False) -> Genome:
+def segdup_families(n_families: int, weight: float = 1.0):
+    """A deterministic list of low-copy segmental-duplication families (2-8 copies of 10-60 kb at 0.5-2.5 % divergence from their
+    template, i.e. 1-5 % between copies) for the repeat-enriched workload of BASELINE.json configs[3]: the families real genomes
+    have many of, next to the few high-copy ones of SURVEY s8d's recipe.  Rows are make_genome's (copies, length, divergence, weight)."""
+    return [(2 + k % 7, 10000 + (k * 7919) % 50000, 0.005 + (k % 5) * 0.005, weight / n_families) for k in range(n_families)]
+
+
+def make_genome(seed: int, contig_lens, repeat_families=None, n_runs: int = 2, alt_contigs: int = 0, fast: bool = False,
+                alt_spec=None, decoy_spec=None) -> Genome:
     """Uniform ACGT contigs + planted repeat families + runs of N.
 
-    repeat_families: list of (copies, length, divergence); defaults scale the SURVEY §8d recipe
-    (Alu-like 300 bp @12%, L1-like 6 kb @5%, segmental duplications 50 kb @1%) to the genome size.
+    repeat_families: list of (copies, length, divergence[, weight]); defaults scale the SURVEY §8d recipe
+    (Alu-like 300 bp @12%, L1-like 6 kb @5%, segmental duplications 50 kb @1%) to the genome size.  The optional weight is
+    only recorded (make_reads' repeat_bias draws molecules from the families in proportion to it).
+    alt_spec = (n, min_len, max_len, divergence): ALT contigs as GRCh38 has them -- diverged copies of slices of the primary
+    contigs, flagged in the .alt file (bntseq.c:98-206; rules at bwamem.c:351, 1078-1082); decoy_spec = (n, length): unflagged
+    decoy contigs of sequence found nowhere else.  Both come from a random stream of their own, so a genome without them is the
+    genome earlier rounds measured.
     """
     rng = np.random.default_rng(seed)
     total = int(sum(contig_lens))
@@ -75,7 +90,9 @@ def make_genome(seed: int, contig_lens, repeat_families=None, n_runs: int = 2, a
             (max(3, int(1e3 * scale * 20)), 6000, 0.05),
             (max(2, int(200 * scale * 10)), 50000, 0.01),
         ]
-    for copies, length, div in repeat_families:
+    planted = []
+    for fi, fam in enumerate(repeat_families):
+        copies, length, div = fam[:3]
         length = int(min(length, min(contig_lens) // 4))
         if length < 50:
             continue
@@ -89,6 +106,7 @@ def make_genome(seed: int, contig_lens, repeat_families=None, n_runs: int = 2, a
             if rng.random() < 0.5:
                 c = (3 - c)[::-1]
             seqs[ci][p:p + length] = c
+            planted.append((fi, ci, p, length))
     for ci in range(len(seqs)):
         for _ in range(n_runs):
             L = len(seqs[ci])
@@ -109,7 +127,28 @@ def make_genome(seed: int, contig_lens, repeat_families=None, n_runs: int = 2, a
         seqs.append(a)
         names.append(f"chrS{(k % len(contig_lens)) + 1}_alt{k + 1}")
         alt.append(True)
-    return Genome(names, seqs, alt)
+    n_prim = len(contig_lens)
+    rng2 = np.random.default_rng([seed, 0xA17])
+    if alt_spec:
+        n_alt, lo, hi, div = alt_spec
+        w = np.array([len(seqs[i]) for i in range(n_prim)], dtype=np.float64)
+        for k in range(int(n_alt)):
+            ci = int(rng2.choice(n_prim, p=w / w.sum()))
+            ln = int(min(rng2.integers(lo, hi + 1), len(seqs[ci]) // 3))
+            p = int(rng2.integers(0, len(seqs[ci]) - ln))
+            a = _mutate(rng2, np.asarray(seqs[ci][p:p + ln]), div)
+            a[a > 3] = 0
+            seqs.append(a)
+            names.append(f"chrS{ci + 1}_KI{270000 + k}v1_alt")
+            alt.append(True)
+    if decoy_spec:
+        n_dec, ln = decoy_spec
+        for k in range(int(n_dec)):
+            seqs.append(rng2.integers(0, 4, size=int(ln), dtype=np.uint8))
+            names.append(f"chrUn_JTFH{1000000 + k}v1_decoy")
+            alt.append(False)
+    fw = np.array([fam[3] if len(fam) > 3 else 1.0 for fam in repeat_families], dtype=np.float64)
+    return Genome(names, seqs, alt, np.array(planted, dtype=np.int64).reshape(-1, 4), fw)
 
 
 @dataclasses.dataclass
@@ -141,10 +180,19 @@ def _revcomp(a):
 
 def make_reads(seed: int, genome: Genome, n_barcodes: int, pairs_per_barcode: int, read_len: int = 150,
                molecules_per_barcode: int = 10, molecule_len: int = 50000, sub_rate: float = 0.005,
-               indel_rate: float = 0.0002, invalid_frac: float = 0.0, repeat_bias=None, fast: bool = False) -> ReadSet:
+               indel_rate: float = 0.0002, invalid_frac: float = 0.0, repeat_bias=None, fast: bool = False,
+               repeat_focus: float = 0.7, barcode_style: str = "haplotag") -> ReadSet:
     """Pairs are FR, insert ~ N(350,50) clipped to >= read_len+10, drawn uniformly inside molecules.
     fast=True (millions of pairs): same distributions, windows gathered as rows of a strided view and substitutions placed by position
-    instead of by a per-base mask -- a different random stream, several times quicker."""
+    instead of by a per-base mask -- a different random stream, several times quicker.
+    repeat_bias (BASELINE.json configs[3]): that fraction of the molecules is drawn from the repeat copies make_genome planted (a
+    family in proportion to its weight, a copy of it uniformly; the molecule covers the copy or lies inside it), and repeat_focus of
+    their pairs have a mate overlapping the copy -- what makes region and candidate lists long.
+    invalid_frac (configs[4]): that fraction of the pairs loses its barcode: VX:i:0, dash-less barcodes shared by 1-4 pairs each,
+    filed among the others in barcode order as a barcode-sorted FASTQ has them -- worthRunningRFA is false for every such group
+    (aligner.go:1018-1030), they take the fallback of aligner.go:469-477.
+    Both draw from random streams of their own: with the defaults the read set is the one earlier rounds measured.
+    barcode_style "stlfr": three-part numeric barcodes a_b_c (the '-1' suffix stays, without it the reference never runs RFA)."""
     rng = np.random.default_rng(seed)
     n_pairs = n_barcodes * pairs_per_barcode
     clen = np.array([len(s) for s in genome.seqs], dtype=np.int64)
@@ -164,6 +212,31 @@ def make_reads(seed: int, genome: Genome, n_barcodes: int, pairs_per_barcode: in
     ins = np.minimum(ins, mlen[mol] - 1)
     ins = np.maximum(ins, read_len)
     fs = mol_s[mol] + (rng.random(n_pairs) * (mlen[mol] - ins)).astype(np.int64)
+    if repeat_bias and genome.copies is not None and len(genome.copies):
+        rb = np.random.default_rng([seed, 0xB1A5])
+        cp = genome.copies
+        fam_w = genome.fam_weight if genome.fam_weight is not None else np.ones(int(cp[:, 0].max()) + 1)
+        per_fam = np.bincount(cp[:, 0], minlength=len(fam_w)).astype(np.float64)
+        wcopy = fam_w[cp[:, 0]] / per_fam[cp[:, 0]]                      # a family by its weight, then one of its copies uniformly
+        biased = np.flatnonzero(rb.random(n_mol) < repeat_bias)
+        pick = rb.choice(len(cp), size=len(biased), p=wcopy / wcopy.sum())
+        b_c, b_p, b_l = cp[pick, 1], cp[pick, 2], cp[pick, 3]
+        b_ml = np.minimum(molecule_len, clen[b_c] - 1)
+        # the molecule covers a copy shorter than itself, and lies inside a longer one
+        lo = np.where(b_l <= b_ml, b_p + b_l - b_ml, b_p)
+        hi = np.where(b_l <= b_ml, b_p, b_p + b_l - b_ml)
+        b_s = np.clip(lo + (rb.random(len(biased)) * (hi - lo + 1)).astype(np.int64), 0, clen[b_c] - b_ml)
+        mol_c = mol_c.copy(); mol_s = mol_s.copy(); mlen = mlen.copy()
+        mol_c[biased], mol_s[biased], mlen[biased] = b_c, b_s, b_ml
+        cp_lo = np.full(n_mol, -1, dtype=np.int64); cp_hi = np.zeros(n_mol, dtype=np.int64)
+        cp_lo[biased] = np.maximum(b_p, b_s); cp_hi[biased] = np.minimum(b_p + b_l, b_s + b_ml)
+        ins = np.maximum(np.minimum(ins, mlen[mol] - 1), read_len)
+        fs = mol_s[mol] + (rb.random(n_pairs) * (mlen[mol] - ins)).astype(np.int64)
+        foc = np.flatnonzero((cp_lo[mol] >= 0) & (rb.random(n_pairs) < repeat_focus))
+        # fragment start so that the fragment overlaps the copy by at least 20 bases, inside the molecule
+        f_lo = np.maximum(cp_lo[mol[foc]] - ins[foc] + 20, mol_s[mol[foc]])
+        f_hi = np.maximum(np.minimum(cp_hi[mol[foc]] - 20, mol_s[mol[foc]] + mlen[mol[foc]] - ins[foc]), f_lo)
+        fs[foc] = f_lo + (rb.random(len(foc)) * (f_hi - f_lo + 1)).astype(np.int64)
     c = mol_c[mol]
     g0 = coff[c] + fs
     flip = rng.random(n_pairs) < 0.5           # which mate is read 1
@@ -212,10 +285,46 @@ def make_reads(seed: int, genome: Genome, n_barcodes: int, pairs_per_barcode: in
         for seg in "ACBD":
             parts.append(f"{seg}{(x % 96) + 1:02d}")
             x //= 96
-        barcodes.append("".join(parts) + "-1")
+        barcodes.append("".join(parts) + "-1" if barcode_style != "stlfr" else f"{b % 1536 + 1}_{(b // 1536) % 1536 + 1}_{b // (1536 * 1536) + 1}-1")
     valid = rng.random(n_pairs) >= invalid_frac
     lens = np.full(2 * n_pairs, read_len, dtype=np.int32)
-    return ReadSet(seqs, lens, bc, barcodes, valid, c.astype(np.int32), fs)
+    rs = ReadSet(seqs, lens, bc, barcodes, valid, c.astype(np.int32), fs)
+    if invalid_frac > 0:
+        rs = _regroup_invalid(np.random.default_rng([seed, 0x1AB]), rs)
+    return rs
+
+
+def _regroup_invalid(rng, rs: ReadSet) -> ReadSet:
+    """The pairs flagged invalid leave their barcodes for dash-less ones shared by 1-4 pairs (consecutive invalid pairs in a random
+    order, so the pairs of a group come from unrelated molecules), and all groups are put in barcode-string order."""
+    inv = np.flatnonzero(~rs.valid)
+    inv = inv[rng.permutation(len(inv))]
+    sizes = []
+    left = len(inv)
+    while left > 0:
+        k = int(min(left, rng.integers(1, 5)))
+        sizes.append(k)
+        left -= k
+    n_old = len(rs.barcodes)
+    grp_of = rs.barcode_id.astype(np.int64).copy()
+    grp_of[inv] = n_old + np.repeat(np.arange(len(sizes)), sizes)
+    letters = "ABCD"
+    new_names = []
+    x = rng.integers(0, 96 ** 4, size=len(sizes))
+    for g in range(len(sizes)):
+        v = int(x[g]); parts = []
+        for seg in "ACBD":
+            parts.append(f"{seg}{(v % 96) + 1:02d}"); v //= 96
+        new_names.append("".join(parts) + f"N{g:06d}")               # no '-': the reference never runs RFA on it, nor emits BX
+    names = list(rs.barcodes) + new_names
+    order_groups = np.argsort(np.array(names, dtype=object), kind="stable")
+    rank = np.empty(len(names), dtype=np.int64); rank[order_groups] = np.arange(len(names))
+    perm = np.argsort(rank[grp_of], kind="stable")                   # pairs by group rank, original order inside a group
+    used = np.unique(rank[grp_of])                                   # a barcode that lost all its pairs disappears
+    remap = np.full(len(names), -1, dtype=np.int64); remap[used] = np.arange(len(used))
+    rows = np.stack([2 * perm, 2 * perm + 1], axis=1).reshape(-1)
+    return ReadSet(rs.seqs[rows], rs.lens[rows], remap[rank[grp_of[perm]]].astype(np.int32), [names[order_groups[u]] for u in used],
+                   rs.valid[perm], rs.truth_contig[perm], rs.truth_pos[perm])
 
 
 def write_fastq(rs: ReadSet, path1: str, path2: str) -> None:

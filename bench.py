@@ -45,6 +45,8 @@ CHR20_LEN = 64_444_167
 GRCH38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
                135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
                50818468, 156040895, 57227415]      # chr1..22, X, Y of GRCh38: 3,088,269,832 bp (a contig must stay below 2^31, bntann1_t.len)
+from arachne_amd.synth import segdup_families  # noqa: E402
+SEGDUP_FAMILIES = segdup_families(300, 0.71)
 WORKLOADS = {
     # name: contig lengths, barcodes, pairs per barcode, molecules per barcode, seed (20250905 + config#), label
     # repeat families at scale 1 are SURVEY.md s8d's recipe as written: 10^4 x 300 bp Alu-like at 12 %, 10^3 x 6 kb L1-like at 5 %,
@@ -55,6 +57,21 @@ WORKLOADS = {
                          "%d barcodes x %d pairs 2x150bp per step per GPU (slice of the 30x set)"),
     "chr20": dict(lens=[CHR20_LEN - 2_000_000, 1_500_000, 500_000], barcodes=1000, ppb=1000, molecules=10, seed=20250905 + 2, families=None,
                   label="BASELINE.json configs[1]: GRCh38 chr20-size genome (%d bp synthetic, planted repeats), %d barcodes x %d pairs 2x150bp per GPU"),
+    # configs[3]: GRCh38 + ALT/decoy contigs (.alt-flagged diverged copies of primary slices, unflagged decoys), repeat-enriched stLFR-like set:
+    # half of the molecules drawn from the planted families (weights: the low-copy segmental duplications real genomes have many of 0.71,
+    # L1-like 0.15, Alu-like 0.1, the 200-copy family 0.04 -- on a scaled-down genome the restatement counts 8 regions per read, median 2,
+    # 99th percentile 107, and 8 rescue alignments per pair, against 1.7 and 0.17 on the TELLseq-like default), 70 % of their pairs
+    # overlapping the copy; stLFR-like barcodes hold few pairs
+    "alt_repeat": dict(lens=GRCH38_LENS, barcodes=33000, ppb=30, molecules=2, seed=20250905 + 4,
+                       families=[(10000, 300, 0.12, 0.1), (1000, 6000, 0.05, 0.15), (200, 50000, 0.01, 0.04)] + SEGDUP_FAMILIES,
+                       alt_spec=(220, 100_000, 900_000, 0.01), decoy_spec=(400, 15_000), reads=dict(repeat_bias=0.5, barcode_style="stlfr"),
+                       label="BASELINE.json configs[3]: GRCh38-size genome + ALT/decoy contigs (%d bp synthetic, 220 .alt-flagged ALT contigs, 400 decoys), "
+                             "repeat-enriched stLFR-like set (half of the molecules from planted repeat families / segmental duplications), %d barcodes x %d pairs 2x150bp per step per GPU"),
+    # configs[4]: configs[1] with 30 % of the pairs VX:i:0 in dash-less barcodes of 1-4 pairs (worthRunningRFA false, aligner.go:469-477,1018-1030)
+    "vxmix": dict(lens=[CHR20_LEN - 2_000_000, 1_500_000, 500_000], barcodes=1000, ppb=1000, molecules=10, seed=20250905 + 5, families=None,
+                  reads=dict(invalid_frac=0.3),
+                  label="BASELINE.json configs[4]: chr20-size genome (%d bp synthetic), %d barcodes x %d pairs 2x150bp per GPU of which 30 %% VX:i:0 in "
+                        "dash-less barcodes of 1-4 pairs (single-read fallback) filed among the RFA barcodes"),
 }
 
 
@@ -62,7 +79,7 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def prepare_index(cache, name, lens, seed, families, rank, barrier, setup, in_child=False):
+def prepare_index(cache, name, lens, seed, families, rank, barrier, setup, in_child=False, alt_spec=None, decoy_spec=None):
     """Synthetic genome + index (built by the product's own `bwa index` equivalent: suffix sorting in HBM), cached on disk.
     The work is done by a child process (bench.py --prepare-only): a process that has synthesised a 3 GB genome and sorted 6.2 G
     suffixes through 125 GB of HBM runs the timed region ~25 % slower afterwards (host-side round trips of the stage loops take longer;
@@ -75,18 +92,22 @@ def prepare_index(cache, name, lens, seed, families, rank, barrier, setup, in_ch
         import subprocess
         os.makedirs(cache, exist_ok=True)
         spec = prefix + ".spec.json"
-        json.dump(dict(cache=cache, name=name, lens=[int(x) for x in lens], seed=int(seed), families=families), open(spec, "w"))
+        json.dump(dict(cache=cache, name=name, lens=[int(x) for x in lens], seed=int(seed), families=families, alt_spec=alt_spec, decoy_spec=decoy_spec), open(spec, "w"))
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--prepare-only", spec])
         setup.update(json.load(open(prefix + ".setup.json")))
     if rank == 0 and not os.path.exists(done):
         os.makedirs(cache, exist_ok=True)
         t = time.time()
-        g = synth.make_genome(seed, lens, repeat_families=families, fast=total > 500_000_000)
+        g = synth.make_genome(seed, lens, repeat_families=families, fast=total > 500_000_000, alt_spec=alt_spec, decoy_spec=decoy_spec)
         setup["genome_synth_s"] = round(time.time() - t, 2)
         t = time.time()
         g.write_fasta(prefix)
+        if any(g.alt):
+            g.write_alt(prefix + ".alt")                 # read by arx_open like bns_restore reads it (bntseq.c:98-206)
         np.save(prefix + ".codes.npy", np.concatenate(g.seqs))
-        np.save(prefix + ".lens.npy", np.array(lens, dtype=np.int64))
+        np.save(prefix + ".lens.npy", np.array([len(x) for x in g.seqs], dtype=np.int64))
+        np.save(prefix + ".copies.npy", g.copies)
+        json.dump(dict(names=g.names, alt=[bool(a) for a in g.alt], fam_weight=[float(x) for x in g.fam_weight]), open(prefix + ".contigs.json", "w"))
         del g
         setup["genome_write_s"] = round(time.time() - t, 2)
         log(f"genome {total} bp synthesised and written in {setup['genome_synth_s'] + setup['genome_write_s']:.1f}s")
@@ -109,7 +130,14 @@ def load_genome(prefix):
     cat = np.load(prefix + ".codes.npy", mmap_mode="r")
     off = np.concatenate([[0], np.cumsum(lens)])
     seqs = [cat[int(off[i]):int(off[i + 1])] for i in range(len(lens))]
-    return synth.Genome([f"chrS{i + 1}" for i in range(len(lens))], seqs, [False] * len(seqs))
+    meta = json.load(open(prefix + ".contigs.json"))
+    return synth.Genome(meta["names"], seqs, meta["alt"], np.load(prefix + ".copies.npy"), np.array(meta["fam_weight"]))
+
+
+def workload_reads(wl, seed, genome, n_barcodes, ppb, fast_above=1_500_000):
+    """The read set of a workload entry (WORKLOADS[...]['reads'] holds what differs from the TELLseq-like default)."""
+    from arachne_amd import synth
+    return synth.make_reads(seed, genome, n_barcodes, ppb, molecules_per_barcode=wl["molecules"], fast=n_barcodes * ppb > fast_above, **wl.get("reads", {}))
 
 
 def cpu_model():
@@ -166,7 +194,8 @@ def go_half_port(rs, ref_out, n, l_pac, ann_off):
         return None
     npairs = int(po[nb])
     sub = refdrv_slice(ref_out, 2 * npairs)
-    flags = [True] * nb
+    from arachne_amd import api
+    flags = [api.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(nb)]
     t = time.time()
     orfa = rfadrv.oracle_rfa(sub, rs.lens[:2 * npairs], po[:nb + 1], flags, l_pac, ann_off)
     secs = time.time() - t
@@ -202,13 +231,13 @@ def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--prepare-only":   # the child of prepare_index()
         sp = json.load(open(sys.argv[2]))
         fam = [tuple(f) for f in sp["families"]] if sp["families"] is not None else None
-        prepare_index(sp["cache"], sp["name"], sp["lens"], sp["seed"], fam, 0, lambda: None, {}, in_child=True)
+        prepare_index(sp["cache"], sp["name"], sp["lens"], sp["seed"], fam, 0, lambda: None, {}, in_child=True, alt_spec=sp.get("alt_spec"), decoy_spec=sp.get("decoy_spec"))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="grch38", choices=sorted(WORKLOADS), help="grch38: the configuration the metric is quoted on (default); chr20: configs[1]")
+    ap.add_argument("--workload", default="grch38", choices=sorted(WORKLOADS), help="grch38: the configuration the metric is quoted on (default); chr20: configs[1]; alt_repeat: configs[3]; vxmix: configs[4]")
     ap.add_argument("--barcodes", type=int, default=0, help="override the workload's barcodes per step")
     ap.add_argument("--pairs-per-barcode", type=int, default=0, help="override the workload's pairs per barcode")
     ap.add_argument("--genome-len", type=int, default=0, help="(experiments) one big contig of this length plus two small ones instead of the workload's genome")
@@ -265,10 +294,11 @@ def main():
     setup = {}
     if args.lib:
         api.LIB_PATH = args.lib
-    prefix = prepare_index(args.cache, args.workload if not args.genome_len else "custom", wl["lens"], SEED0, wl["families"], rank, barrier, setup)
+    prefix = prepare_index(args.cache, args.workload if not args.genome_len else "custom", wl["lens"], SEED0, wl["families"], rank, barrier, setup,
+                           alt_spec=wl.get("alt_spec"), decoy_spec=wl.get("decoy_spec"))
     genome = load_genome(prefix)
     t = time.time()
-    rs = synth.make_reads(SEED0 + 1000 * (rank + 1), genome, n_barcodes, ppb, molecules_per_barcode=wl["molecules"], fast=n_barcodes * ppb > 1_500_000)
+    rs = workload_reads(wl, SEED0 + 1000 * (rank + 1), genome, n_barcodes, ppb)
     setup["reads_synth_s"] = round(time.time() - t, 2)
     log(f"rank {rank}: {rs.n_pairs} pairs synthesised in {time.time() - t:.1f}s")
     del genome
@@ -417,11 +447,12 @@ def main():
         packed = assign = None
         if rank == 0:   # the ingest rank holds every rank's barcodes (the same read sets the ranks synthesised for themselves)
             genome = load_genome(prefix)
-            sets_all = [rs] + [synth.make_reads(SEED0 + 1000 * (r + 1), genome, n_barcodes, ppb, molecules_per_barcode=wl["molecules"], fast=n_barcodes * ppb > 1_500_000) for r in range(1, world)]
+            sets_all = [rs] + [workload_reads(wl, SEED0 + 1000 * (r + 1), genome, n_barcodes, ppb) for r in range(1, world)]
             del genome
             seqs_all = np.concatenate([x.seqs for x in sets_all]); lens_all = np.concatenate([x.lens for x in sets_all])
             po_all = np.concatenate([[0]] + [x.pair_offsets()[1:] + i * rs.n_pairs for i, x in enumerate(sets_all)]).astype(np.int64)
-            flags_all = np.array([api.worth_running_rfa(rs.barcodes[i % len(rs.barcodes)], int(po_all[i + 1] - po_all[i])) for i in range(len(po_all) - 1)], dtype=np.uint8)
+            names_all = [nm for x in sets_all for nm in x.barcodes]
+            flags_all = np.array([api.worth_running_rfa(names_all[i], int(po_all[i + 1] - po_all[i])) for i in range(len(po_all) - 1)], dtype=np.uint8)
             assign = shard.lpt_assign(np.diff(po_all), world)
             packed = [shard.pack(seqs_all, lens_all, po_all, flags_all, a) for a in assign]
             del sets_all, seqs_all
@@ -509,7 +540,7 @@ def main():
                 launches_per_batch = 2.0
                 avg_ms = ms / calls
                 bytes_per_launch = ab["bwd"] * reads_per_launch / launches_per_batch
-                achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                achieved = bytes_per_launch / max(avg_ms * 1e-3, 1e-12) / 1e9
                 # memory-side bytes of the same kernels from the committed rocprofv3 --pmc FETCH_SIZE pass of this command (counters
                 # cannot be read from inside the process); null when no such pass is committed
                 traffic, traffic_src = None, None
@@ -527,7 +558,7 @@ def main():
                 ims, icalls = group(ktimes_iso, BWD)
                 if icalls:
                     iso_ms = ims / icalls
-                    iso = bytes_per_launch / (iso_ms * 1e-3) / 1e9
+                    iso = bytes_per_launch / max(iso_ms * 1e-3, 1e-12) / 1e9
                     out["roofline"]["isolated"] = dict(achieved=iso, frac=iso / HBM_PEAK_GBS, avg_launch_ms=iso_ms,
                                                        note="same kernels, same inputs, launched alone after the timed region (in the timed region they co-run with the other batches' DP kernels)")
             # the whole seeding stage (forward extensions, backward sweeps, third pass, gathers) against its algorithmic bytes
@@ -537,19 +568,19 @@ def main():
                 runs = kt["seed_strat"]["calls"] if "seed_strat" in kt else 0
                 if runs:
                     tot = (ab["seed"] + ab["strat"]) * reads_per_launch
-                    ach = tot / (sms / runs * 1e-3) / 1e9
+                    ach = tot / max(sms / runs * 1e-3, 1e-12) / 1e9
                     out[key] = dict(kernels=stage, bound=bound, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                                     algorithmic_bytes_per_read=ab["seed"] + ab["strat"], ms_per_batch=sms / runs)
             ms, calls = group(ktimes, ["seed_fwd"])
             if calls:
                 avg_ms = ms / calls
-                ach = ab["fwd"] * reads_per_launch / 2.0 / (avg_ms * 1e-3) / 1e9
+                ach = ab["fwd"] * reads_per_launch / 2.0 / max(avg_ms * 1e-3, 1e-12) / 1e9
                 out["roofline_fwd"] = dict(kernel="seed_fwd (k_seed_fwd1 / k_seed_fwd2: forward extensions of bwt_smem1a)", bound=bound, achieved=ach, peak=HBM_PEAK_GBS,
                                            unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["fwd"], avg_launch_ms=avg_ms)
             ks3 = ktimes.get("seed_strat")
             if ks3 and ks3["calls"]:
                 avg_ms = ks3["ms"] / ks3["calls"]
-                ach = ab["strat"] * reads_per_launch / (avg_ms * 1e-3) / 1e9
+                ach = ab["strat"] * reads_per_launch / max(avg_ms * 1e-3, 1e-12) / 1e9
                 out["roofline_strat"] = dict(kernel="seed_strat (k_strat_dyn: bwt_seed_strategy1, third seeding pass)", bound=bound, achieved=ach, peak=HBM_PEAK_GBS,
                                              unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=ab["strat"], avg_launch_ms=avg_ms)
             kl = ktimes.get("locate")
@@ -559,11 +590,47 @@ def main():
                 # device's sample interval (counted by the restatement for 8; the reference's own walk to every 32nd row beside it)
                 dense = int(os.environ.get("ARX_SA_DENSE", "8"))
                 per_read = ab["locate8"] if dense == 8 else ab["locate"]
-                ach = per_read * reads_per_launch / (avg_ms * 1e-3) / 1e9
+                ach = per_read * reads_per_launch / max(avg_ms * 1e-3, 1e-12) / 1e9
                 out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk to the suffix-array sample every %d-th row)" % dense, bound=bound,
                                               achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=per_read,
                                               reference_walk_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms)
             out["work_per_read"] = ab["counters"]
+            cw = ab["counters"]
+            # SURVEY.md s8d's path-level figure: pairs/s x algorithmic bytes per pair / HBM peak, bytes per read =
+            # 64 (E1 + 2 E2) + (64 S + 8 N_sa) + L/4 + 88 N_reg, all counted by the instrumented restatement on a sample of the same reads
+            per_read = 64.0 * (cw["ext_same_block"] + 2 * cw["ext_two_block"]) + 64.0 * cw["sa_lf_steps"] + 8.0 * cw["sa_lookups"] + float(np.mean(rs.lens)) / 4 + 88.0 * cw["n_regs"]
+            out["roofline_path"] = dict(definition="SURVEY.md s8d: pairs/s x algorithmic bytes per pair / HBM peak; bytes per read = 64(E1+2E2) + 64 S + 8 N_sa + L/4 + 88 N_reg "
+                                                   "(the reference's own walks, incl. its suffix-array sample every 32nd row)",
+                                        algorithmic_bytes_per_pair=2 * per_read, achieved=value * 2 * per_read / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=value * 2 * per_read / 1e9 / HBM_PEAK_GBS)
+            # Smith-Waterman kernels: cell updates per second (the reference's cells, counted by the restatement: band cells of ksw_extend2,
+            # query x window cells of both ksw_u8 passes, band cells of ksw_global2) against the VALU; instruction counters from the committed
+            # rocprofv3 --pmc pass of this command (profiles/r03/sw_counters_<workload>.json, tools/prof_summary.py), null when none is committed
+            swc = {}
+            rel_sw = os.path.join("profiles", "r03", "sw_counters_%s.json" % args.workload)
+            if os.path.exists(os.path.join(ROOT, rel_sw)):
+                swc = json.load(open(os.path.join(ROOT, rel_sw)))
+            sw = {}
+            for key, kern, cells_key, what in (("extend", "extend", "cells_extend", "ksw_extend2 band cells (k_extend_g16)"), ("sw_u8", "sw_u8", "cells_u8", "ksw_u8 cells, both passes (k_sw_u8_g16)"),
+                                               ("reg2aln_nw", "reg2aln_nw", "cells_global", "ksw_global2 band cells (k_reg2aln_nw_g16)")):
+                cells_step = cw[cells_key] * 2.0 * rs.n_pairs
+                e = dict(cells=what, cells_per_read=cw[cells_key])
+                if kern in ktimes and ktimes[kern]["ms"] > 0:
+                    e["gcups_timed"] = cells_step * args.steps / (ktimes[kern]["ms"] * 1e-3) / 1e9
+                if kern in ktimes_alone and ktimes_alone[kern]["ms"] > 0:
+                    e["gcups_alone"] = cells_step / (ktimes_alone[kern]["ms"] * 1e-3) / 1e9
+                e.update(swc.get(kern, dict(valu_busy=None, lane_ops_per_cell=None, lds_insts_per_valu=None)))
+                sw[key] = e
+            out["roofline_sw"] = dict(kernels=sw, bound="valu", counters_source=rel_sw if swc else None,
+                                      peak_note="gfx950: 256 CUs x 4 SIMDs; valu_busy = rocprofv3's VALUBusy (SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles at %.1f GHz); "
+                                                "lane_ops_per_cell = SQ_INSTS_VALU x 64 / reference cells; max-plus DP, no MFMA" % 2.4)
+            if "roofline" in out:   # what the committed counters say the roofline kernel is bound by
+                rc = swc.get("seed_bwd")
+                if rc and rc.get("valu_busy") is not None:
+                    out["roofline"]["valu_busy"] = rc["valu_busy"]
+                    if rc["valu_busy"] >= 0.6 and in_hbm:
+                        out["roofline"]["bound"] = "valu"
+                        out["roofline"]["bound_note"] += "; the kernel's vector instructions keep the SIMDs busy %.0f %% of its time (VALUBusy, committed --pmc pass): instruction issue, not HBM, bounds it; frac stays the HBM-roofline figure the metric asks for" % (100 * rc["valu_busy"])
         except Exception as e:  # the roofline needs the oracle library; never fail the throughput line over it
             log("roofline skipped:", repr(e))
         tot = sum(v["ms"] for v in ktimes.values()) or 1.0
@@ -585,6 +652,26 @@ def main():
         out["rounds"] = dict(ext=max(c["ext_rounds"] for c in counts), rescue=max(c["rescue_rounds"] for c in counts),
                              ext_dp_per_pair=sum(c["n_ext"] for c in counts) / rs.n_pairs, sw_per_pair=sum(c["n_sw"] for c in counts) / rs.n_pairs,
                              regs_per_read=sum(c["n_regs"] for c in counts) / (2.0 * rs.n_pairs))
+        out["rccl_ranks"] = world if (dist is not None and args.backend == "nccl") else 0
+        # the boundary pass handed the same reads over from host memory (arx_batch_reset) and took the results back (arx_batch_fetch +
+        # arx_batch_rfa_fetch into reused arrays): its last step's output of the first batch must equal the resident run's, byte for byte
+        if boundary and not args.no_rfa and batches[0].out and not scatter_info:
+            b0 = batches[0]
+            c0 = b0.counts()
+            res_out = b0.fetch()
+            res_c = np.zeros(b0._n_cands, dtype=api.CAND_DTYPE); res_off = np.zeros(b0.n_reads + 1, dtype=np.int32)
+            ref._check(ref.lib.arx_batch_rfa_fetch(ref.h, b0.h, res_off.ctypes.data, res_c.ctypes.data))
+            same = (np.array_equal(b0.out["reg_off"][:b0.n_reads + 1], res_out["reg_off"]) and np.array_equal(b0.out["regs"][:c0["n_regs"]], res_out["regs"])
+                    and np.array_equal(b0.out["alns"][:c0["n_regs"]], res_out["alns"]) and np.array_equal(b0.out["cigars"][:c0["n_cigar"]], res_out["cigars"])
+                    and np.array_equal(b0.out["cand_off"][:b0.n_reads + 1], res_off) and b0.out["cands"][:b0._n_cands].tobytes() == res_c.tobytes())
+            out["boundary"]["matches_resident"] = bool(same)
+            if not same:
+                parity_failed = "boundary pass (arx_batch_reset / fetch_into) differs from the resident run on the first device batch"
+        out["parity_ok"] = None if parity_failed is None else False
+        if world != 1:
+            out["parity_skipped"] = "N > 1: the CPU leg and the parity gate run on the N = 1 line only"
+        elif args.no_cpu_baseline:
+            out["parity_skipped"] = "--no-cpu-baseline"
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             n_sample = args.cpu_sample or min(rs.n_pairs, 2000 * cores)
@@ -595,6 +682,7 @@ def main():
                 out["cpu_baseline"] = cb
             except (ImportError, OSError, RuntimeError) as e:   # the baseline library is missing or cannot load the index: report, keep the throughput line
                 log("cpu baseline skipped:", repr(e))
+                out["parity_skipped"] = "the CPU baseline library could not run: " + repr(e)[:200]
             if ref_out is not None:
                 # The same sample through the GPU path must agree with the CPU path it is timed beside: regions, positions, strands, NM and
                 # CIGARs against the reference's C core, candidates / placement / MAPQ against the restatement of the Go half run on the
@@ -615,7 +703,7 @@ def main():
                         parity.check_rfa(b.rfa(bpo, flags), orfa)
                         out["parity_checked_rfa_barcodes"] = len(flags)
                     b.free()
-                    out["parity_ok"] = True
+                    out["parity_ok"] = parity_failed is None
                 except AssertionError as e:
                     out["parity_ok"] = False
                     out["parity_error"] = str(e)[:500]

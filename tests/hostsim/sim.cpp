@@ -142,6 +142,7 @@ struct SimRT {
 	template <class F> void launch_wide(const char *nm, int n, const F &f) { launch(nm, n, f); }
 	template <class F> void launch_block(const char *nm, int n, const F &f, const uint8_t * = nullptr) { tm[nm].calls++; tm[nm].items += n; SimBlock blk; for (int i = 0; i < n; ++i) f(i, blk); }
 	template <class F> void launch_cold(const char *nm, int n, const F &f) { launch(nm, n, f); }
+	void merge_sort_fail(uint32_t *err) { if (g_arx_sort_fail) *err |= ERR_INTERNAL; }
 	template <class F> void run_sw_u8(const char *nm, int n, const F &f, int max_len) { launch_rows(nm, n, f, 16 * ((max_len + 15) / 16)); }
 	template <class F> void run_seed_fwd1(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }
 	template <class F> void run_seed_fwd2(const char *nm, int n, const F &f, int32_t *) { launch(nm, n, f); }

@@ -26,16 +26,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SIM = os.path.join(HERE, "hostsim", "libarx_hostsim.so")
 
 
-def _build(g):
+def _build(g, alt=False):
     d = tempfile.mkdtemp(prefix="arx_shape_")
     fa = os.path.join(d, "g.fa")
     g.write_fasta(fa)
+    if alt:
+        g.write_alt(fa + ".alt")
     return fa
 
 
-def _run_and_check(lib_path, g, rs, do_rfa=None, post=True, stages=False, threads=8):
+def _run_and_check(lib_path, g, rs, do_rfa=None, post=True, stages=False, threads=8, alt=False, also_ref=False):
     import oradrv
-    fa = _build(g)
+    fa = _build(g, alt)
     api.index_build(fa, fa, lib_path=lib_path if lib_path != SIM else api.LIB_PATH)
     o = oradrv.Oracle(fa)
     ref = api.Reference(fa, lib_path=lib_path)
@@ -52,6 +54,12 @@ def _run_and_check(lib_path, g, rs, do_rfa=None, post=True, stages=False, thread
             parity.check_core(b, o, rs.seqs, rs.lens, reads=heavy)
         dev = b.fetch()
         parity.check_final(dev, ob)
+        if also_ref:
+            import refdrv
+            if refdrv.available():                                       # the reference's own C core on the same reads
+                r = refdrv.Ref(fa)
+                parity.check_final(dev, r.batch(rs.seqs, rs.lens, n_threads=threads))
+                r.close()
         ora = rfadrv.oracle_rfa(ob, rs.lens, po, flags, l_pac, offs)
         cands = b.rfa(po, flags)
         parity.check_rfa(cands, ora)
@@ -233,6 +241,80 @@ def _assert_ties_present_and_first_wins(cands):
     assert tied_reads >= 10, tied_reads
 
 
+# ---- BASELINE.json configs[3]: ALT/decoy contigs + repeat-enriched stLFR-like set; configs[4]: 30 % VX:i:0 dash-less small groups
+def _config3_workload(seed, primary_lens, n_alt, n_bc, ppb, n_segdup):
+    """bench.py's alt_repeat recipe scaled down: the three families of SURVEY s8d + low-copy segmental duplications, .alt-flagged ALT
+    contigs (diverged copies of primary slices: bwamem.c:351, 1078-1082), unflagged decoys; half of the molecules drawn from the
+    planted copies, stLFR-like barcodes of few pairs."""
+    total = sum(primary_lens)
+    scale = total / 3.1e9
+    fams = [(max(8, int(1e4 * scale * 4)), 300, 0.12, 0.1), (max(6, int(1e3 * scale * 4)), 6000, 0.05, 0.15), (max(12, int(200 * scale * 8)), 30000, 0.01, 0.04)] + \
+        synth.segdup_families(n_segdup, 0.71)
+    g = synth.make_genome(seed, list(primary_lens), repeat_families=fams, alt_spec=(n_alt, 20_000, 120_000, 0.01), decoy_spec=(3, 8000))
+    rs = synth.make_reads(seed + 1, g, n_bc, ppb, molecules_per_barcode=2, repeat_bias=0.5, barcode_style="stlfr")
+    return g, rs
+
+
+def _assert_config3_shape(g, rs, dev, ob, mean_min=3.0, max_min=20):
+    assert sum(g.alt) >= 2                         # ALT contigs are in the index ...
+    assert int((dev["regs"]["is_alt"] != 0).sum()) > 0, "no region landed on an ALT contig"
+    nreg = np.diff(ob["reg_off"])
+    assert nreg.mean() >= mean_min and nreg.max() >= max_min, (nreg.mean(), nreg.max())   # ... and the lists are long
+
+
+def test_config3_alt_repeat_stlfr_hostsim(built):
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    g, rs = _config3_workload(20250905 + 4, [900_000, 500_000], 3, 8, 14, 4)
+    dev, cands, ob = _run_and_check(SIM, g, rs, alt=True)
+    _assert_config3_shape(g, rs, dev, ob, 2.0, 10)
+
+
+@pytest.mark.gpu
+def test_config3_alt_repeat_stlfr_50Mbp_20k_pairs_gpu(built):
+    """configs[3] at reduced size: 50 Mbp of primary contigs + 12 ALT contigs + decoys, 20,000 pairs in 666 stLFR-like barcodes, against the
+    restatement AND the compiled reference (regions .. CIGARs), RFA / MAPQ / post passes against the Go-half restatement."""
+    g, rs = _config3_workload(20250905 + 4, [30_000_000, 15_000_000, 5_000_000], 12, 666, 30, 20)
+    dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, alt=True, threads=32, also_ref=True)
+    _assert_config3_shape(g, rs, dev, ob)
+
+
+def _config4_workload(seed, genome_len, n_bc, ppb):
+    g = synth.make_genome(seed, [genome_len - 200_000, 150_000, 50_000] if genome_len > 1_000_000 else [genome_len])
+    rs = synth.make_reads(seed + 1, g, n_bc, ppb, invalid_frac=0.3)
+    return g, rs
+
+
+def _assert_config4_shape(rs, cands):
+    po = rs.pair_offsets()
+    sizes = np.diff(po)
+    flags = np.array([rfadrv.worth_running_rfa(rs.barcodes[b], int(sizes[b])) for b in range(len(sizes))])
+    small = ~flags
+    assert small.sum() >= 10 and sizes[small].max() <= 4 and all("-" not in rs.barcodes[b] for b in np.flatnonzero(small))
+    share = sizes[small].sum() / rs.n_pairs
+    assert 0.2 < share < 0.4, share
+    # the fallback leaves the candidates un-placed by RFA: no molecule, and exactly one active candidate per read all the same
+    c = cands["cands"]
+    for b in np.flatnonzero(small)[:50]:
+        rows = c[cands["cand_off"][2 * po[b]]:cands["cand_off"][2 * po[b + 1]]]
+        assert (rows["molecule_id"] == -1).all() and int(rows["active"].sum()) == 2 * int(sizes[b])
+
+
+def test_config4_vx0_small_groups_hostsim(built):
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    g, rs = _config4_workload(20250905 + 5, 600_000, 3, 110)
+    dev, cands, ob = _run_and_check(SIM, g, rs)
+    _assert_config4_shape(rs, cands)
+
+
+@pytest.mark.gpu
+def test_config4_vx0_small_groups_20k_pairs_gpu(built):
+    """configs[4] at reduced size: 20,000 pairs on a 20 Mbp genome, 30 % of them in ~2,400 dash-less groups of 1-4 pairs filed among 20 RFA
+    barcodes; every field against the restatements and the compiled reference."""
+    g, rs = _config4_workload(20250905 + 5, 20_000_000, 20, 1000)
+    dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, threads=32, also_ref=True)
+    _assert_config4_shape(rs, cands)
+
+
 def _fullsize(workload, tmp):
     """tools/gpu_fullsize_check.py on a bench workload at its full step size: two batch shapes give identical digests of every
     per-read output; then a slice of the same reads against the oracle AND the compiled reference, with RFA against the restatement."""
@@ -264,7 +346,7 @@ def _fullsize(workload, tmp):
             parity.check_final(b.fetch(), r.batch(seqs, lens, n_threads=16))
             r.close()
         names, offs, clens, alt, l_pac = ref.contigs()
-        flags = [True] * nb
+        flags = [rfadrv.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(nb)]
         parity.check_rfa(b.rfa(po[:nb + 1], flags), rfadrv.oracle_rfa(ob, lens, po[:nb + 1], flags, l_pac, offs))
         b.free()
         o.close()
@@ -283,3 +365,17 @@ def test_config2_grch38_size_slice_full_step_gpu(built, tmp_path_factory):
     """BASELINE.json configs[2] on one GPU: the GRCh38-size index (built in HBM by arx_index_build) and one full bench step
     (13,000 TELLseq-like barcodes x 77 pairs); the slice check loads the 5.4 GB index into the reference's C core as well."""
     _fullsize("grch38", tmp_path_factory.mktemp("grch38"))
+
+
+@pytest.mark.gpu
+def test_config3_alt_repeat_full_step_gpu(built, tmp_path_factory):
+    """BASELINE.json configs[3] at full size: GRCh38-size genome + 220 ALT contigs + 400 decoys, one full bench step of 33,000
+    stLFR-like barcodes x 30 pairs, half of the molecules in planted repeats: two batch shapes give identical digests of every
+    per-read output, then a slice against the restatements and the compiled reference."""
+    _fullsize("alt_repeat", tmp_path_factory.mktemp("alt_repeat"))
+
+
+@pytest.mark.gpu
+def test_config4_vxmix_full_step_gpu(built, tmp_path_factory):
+    """BASELINE.json configs[4] at full size: 1 M pairs, 30 % of them in ~120,000 dash-less groups of 1-4 pairs among 1,000 RFA barcodes."""
+    _fullsize("vxmix", tmp_path_factory.mktemp("vxmix"))

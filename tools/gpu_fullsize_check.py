@@ -19,9 +19,9 @@ def fullsize_check(workload="chr20", n_bc=0, ppb=0, cache="/tmp/arx_bench_cache"
     """-> (ok, digests, stats, (ref, read set, index prefix)); the caller closes ref"""
     wl = bench.WORKLOADS[workload]
     n_bc, ppb = n_bc or wl["barcodes"], ppb or wl["ppb"]
-    prefix = bench.prepare_index(cache, workload, wl["lens"], wl["seed"], wl["families"], 0, lambda: None, {})
+    prefix = bench.prepare_index(cache, workload, wl["lens"], wl["seed"], wl["families"], 0, lambda: None, {}, alt_spec=wl.get("alt_spec"), decoy_spec=wl.get("decoy_spec"))
     genome = bench.load_genome(prefix)
-    rs = synth.make_reads(wl["seed"] + 1000, genome, n_bc, ppb, molecules_per_barcode=wl["molecules"], fast=n_bc * ppb > 500_000)
+    rs = bench.workload_reads(wl, wl["seed"] + 1000, genome, n_bc, ppb, fast_above=500_000)
     del genome
     ref = api.load_reference(prefix, 0)
     po = rs.pair_offsets()

@@ -74,6 +74,36 @@ try:
     print("seed traffic per read:", {k: round(v) for k, v in traffic.items() if k.endswith("per_read")}, "algorithmic:", traffic["algorithmic"])
 except Exception as e:
     print("seed traffic not derived:", repr(e))
+# VALU / LDS figures of the DP kernels and of the roofline kernel (bench.py's roofline_sw and roofline.bound read this file from profiles/r03/)
+try:
+    bp = res.get("bench_plain", {})
+    ks_ = {r["kernel"]: r for r in res.get("kernel_stats", [])}
+    passes = bp["steps"] + bp["warmup"] + 1                  # whole-path passes over the read set in the profiled command (timed + warm-up + the "alone" pass)
+    reads = 2.0 * bp["config"]["pairs_per_step_per_gpu"]
+    groups = {"extend": (["k_extend_g16<4>", "k_extend_g16<7>", "k_extend_g16<10>", "k_extend_g16<16>", "k_extend_classes", "k_extend_b16<4>", "k_extend_b16<7>", "k_extend_b16<10>", "k_extend_b16<16>"], "cells_extend"),
+              "sw_u8": (["k_sw_u8_g16<10>", "k_sw_u8_g16<16>"], "cells_u8"), "reg2aln_nw": (["k_reg2aln_nw_g16"], "cells_global"),
+              "seed_bwd": (["k_seed_bwd_g"], None), "seed_fwd": (["k_seed_fwd1", "k_seed_fwd2"], None), "seed_strat": (["k_strat_dyn"], None), "locate": (["k_locate_dyn"], None)}
+    swc = {}
+    for key, (names, cells_key) in groups.items():
+        have = [k for k in names if k in pmc and "SQ_INSTS_VALU" in pmc[k]]
+        if not have:
+            continue
+        valu = sum(pmc[k]["SQ_INSTS_VALU"] for k in have); act = sum(pmc[k].get("SQ_ACTIVE_INST_VALU", 0.0) for k in have)
+        lds = sum(pmc[k].get("SQ_INSTS_LDS", 0.0) for k in have); salu = sum(pmc[k].get("SQ_INSTS_SALU", 0.0) for k in have)
+        wait = sum(pmc[k].get("SQ_WAIT_ANY", 0.0) for k in have); wcyc = sum(pmc[k].get("SQ_WAVE_CYCLES", 0.0) for k in have)
+        total_ns = sum(ks_[k]["total_ms"] for k in have if k in ks_) * 1e6
+        e = dict(kernels=have, SQ_INSTS_VALU=valu, SQ_INSTS_LDS=lds, SQ_INSTS_SALU=salu, trace_total_ms=total_ns / 1e6,
+                 valu_busy=(act * 4.0 / (1024.0 * total_ns * 2.4)) if total_ns else None,     # rocprofv3's VALUBusy: SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles
+                 lds_insts_per_valu=lds / valu if valu else None, wait_share=wait / wcyc if wcyc else None)
+        if cells_key:
+            cells = bp["work_per_read"][cells_key] * reads * passes
+            e["lane_ops_per_cell"] = valu * 64.0 / cells if cells else None
+            e["reference_cells_in_profiled_run"] = cells
+        swc[key] = e
+    json.dump(swc, open(os.path.join(out, "sw_counters.json"), "w"), indent=1)
+    print("sw counters:", {k: {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if a in ("valu_busy", "lane_ops_per_cell", "lds_insts_per_valu", "wait_share")} for k, v in swc.items()})
+except Exception as e:
+    print("sw counters not derived:", repr(e))
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 ks = {r["kernel"]: r for r in res.get("kernel_stats", [])}
 print("kernel trace (avg ms per launch):", {k: round(v["avg_ms"], 3) for k, v in list(ks.items())[:12]})
