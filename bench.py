@@ -289,7 +289,7 @@ def main():
     if args.genome_len:
         wl["lens"] = [args.genome_len - 2_000_000, 1_500_000, 500_000] if args.genome_len > 8_000_000 else [args.genome_len]
     n_barcodes, ppb = args.barcodes or wl["barcodes"], args.pairs_per_barcode or wl["ppb"]
-    genome_len = int(sum(wl["lens"]))
+    genome_len = int(sum(wl["lens"]))       # primary contigs; ALT / decoy contigs come on top (index_bytes_in_files has the whole index)
     SEED0 = wl["seed"]
     setup = {}
     if args.lib:

@@ -275,7 +275,7 @@ def test_config3_alt_repeat_stlfr_50Mbp_20k_pairs_gpu(built):
     restatement AND the compiled reference (regions .. CIGARs), RFA / MAPQ / post passes against the Go-half restatement."""
     g, rs = _config3_workload(20250905 + 4, [30_000_000, 15_000_000, 5_000_000], 12, 666, 30, 20)
     dev, cands, ob = _run_and_check(api.LIB_PATH, g, rs, alt=True, threads=32, also_ref=True)
-    _assert_config3_shape(g, rs, dev, ob)
+    _assert_config3_shape(g, rs, dev, ob, 2.5, 20)
 
 
 def _config4_workload(seed, genome_len, n_bc, ppb):
