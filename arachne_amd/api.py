@@ -76,7 +76,7 @@ def _load(path):
     lib.arx_batch_debug_intv.argtypes = [vp, vp, vp, vp]
     lib.arx_batch_debug_chains.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.arx_batch_debug_core.argtypes = [vp, vp, vp, vp]
-    lib.arx_batch_rfa.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.arx_batch_rfa.argtypes = [vp, vp, i32, vp, vp, C.c_double, vp, vp, vp]
     lib.arx_batch_rfa_fetch.argtypes = [vp, vp, vp, vp]
     lib.arx_batch_post.argtypes = [vp, vp, vp]
     lib.arx_batch_post_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -88,6 +88,11 @@ def _load(path):
     lib.arx_bam_close.argtypes = [vp, vp]
     lib.arx_bam_error.restype = C.c_char_p
     lib.arx_bam_error.argtypes = [vp]
+    lib.arx_recbuf_create.argtypes = [C.POINTER(vp)]
+    lib.arx_recbuf_build.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.arx_recbuf_error.restype = C.c_char_p
+    lib.arx_recbuf_error.argtypes = [vp]
+    lib.arx_recbuf_free.argtypes = [vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     lib.arx_selftest_wave_sort.argtypes = [i32, i32, C.c_int64, vp]
@@ -153,6 +158,15 @@ class Batch:
             self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, buf["cand_off"].ctypes.data, buf["cands"].ctypes.data))
         return c
 
+    def post_into(self, buf):
+        """arx_batch_post + arx_batch_post_fetch of the per-candidate records into buf["post"] (grown when needed)."""
+        n = C.c_int64()
+        self.ref._check(self.ref.lib.arx_batch_post(self.ref.h, self.h, C.byref(n)))
+        if "post" not in buf or len(buf["post"]) < self._n_cands:
+            buf["post"] = np.zeros(int(self._n_cands * 1.2) + 16, dtype=POST_DTYPE)
+        self.ref._check(self.ref.lib.arx_batch_post_fetch(self.ref.h, self.h, buf["post"].ctypes.data, None, None, None))
+        return buf["post"]
+
     def run(self, last_stage=STAGE_ALN):
         self.ref._check(self.ref.lib.arx_batch_run(self.ref.h, self.h, last_stage))
         return self
@@ -203,7 +217,7 @@ class Batch:
             cs = np.ascontiguousarray(centromeres[0], dtype=np.int64)
             ce = np.ascontiguousarray(centromeres[1], dtype=np.int64)
         n = C.c_int64()
-        self.ref._check(self.ref.lib.arx_batch_rfa(self.ref.h, self.h, len(bco) - 1, bco.ctypes.data, flags.ctypes.data, int(penalty),
+        self.ref._check(self.ref.lib.arx_batch_rfa(self.ref.h, self.h, len(bco) - 1, bco.ctypes.data, flags.ctypes.data, float(penalty),
                                                    cs.ctypes.data if cs is not None else None, ce.ctypes.data if ce is not None else None, C.byref(n)))
         self._n_cands = int(n.value)
         if not fetch:
@@ -284,6 +298,25 @@ class Feeder:
                     rgs=[rgs[rg_off[i]:rg_off[i + 1]].decode() for i in range(P)],
                     barcodes=[bcs[bc_off[i]:bc_off[i + 1]].decode() for i in range(n)])
 
+    def next_raw(self, target_pairs: int):
+        """-> (_SuperBatch, views) without copying, or None at the end of the input.  The struct goes to RecBuf.build as it is; views are
+        numpy arrays over the feeder's own memory (bases, lens, set_pair_off, do_rfa: what arx_batch_create / arx_batch_reset and
+        arx_batch_rfa take).  Everything is valid until the next call on this feeder."""
+        sb = _SuperBatch()
+        n = self.lib.arx_feeder_next(self.h, int(target_pairs), C.byref(sb))
+        if n < 0:
+            raise ArachneError("arx_feeder_next: read error")
+        if n == 0:
+            return None
+
+        def view(ptr, count, ct, dt):
+            return np.frombuffer((ct * count).from_address(ptr), dtype=dt) if count else np.zeros(0, dtype=dt)
+        P = sb.n_pairs
+        lens = view(sb.lens, 2 * P, C.c_int32, np.int32)
+        nb = int(lens.sum(dtype=np.int64))
+        return sb, dict(n_sets=n, n_pairs=P, lens=lens, bases=view(sb.bases, nb, C.c_uint8, np.uint8), set_pair_off=view(sb.set_pair_off, n + 1, C.c_int64, np.int64),
+                        do_rfa=view(sb.do_rfa, n, C.c_uint8, np.uint8))
+
     def close(self):
         if self.h:
             self.lib.arx_feeder_close(self.h)
@@ -336,6 +369,11 @@ class BamWriter:
         if self.lib.arx_bam_write(self.h, C.byref(b)) != 0:
             raise ArachneError("arx_bam_write: " + self.lib.arx_bam_error(self.h).decode())
 
+    def write_view(self, view):
+        """a _BamBatch as RecBuf.build returns it"""
+        if self.lib.arx_bam_write(self.h, C.byref(view)) != 0:
+            raise ArachneError("arx_bam_write: " + self.lib.arx_bam_error(self.h).decode())
+
     def close(self):
         st = np.zeros(4, dtype=np.int64)
         if self.h:
@@ -344,6 +382,37 @@ class BamWriter:
             if rc != 0:
                 raise ArachneError("arx_bam_close failed")
         return dict(records=int(st[0]), blocks=int(st[1]), bytes_in=int(st[2]), bytes_out=int(st[3]))
+
+
+class RecBuf:
+    """From the path's results to BAM records (arx_recbuf_*): the primary record of every read of a super-batch, built on host threads;
+    the view it returns goes to BamWriter.write_view.  Host code of the product library."""
+
+    def __init__(self, lib_path: str = LIB_PATH):
+        self.lib = _load(lib_path)
+        self.h = C.c_void_p()
+        if self.lib.arx_recbuf_create(C.byref(self.h)) != 0:
+            raise ArachneError("arx_recbuf_create failed")
+
+    def build(self, sb, cand_off, cands, alns, cigars, post=None, threads: int = 8):
+        """sb: the _SuperBatch of Feeder.next_raw; the arrays as Batch.fetch_into / Batch.post leave them -> _BamBatch view"""
+        view = _BamBatch()
+        rc = self.lib.arx_recbuf_build(self.h, C.byref(sb), cand_off.ctypes.data, cands.ctypes.data, alns.ctypes.data, cigars.ctypes.data,
+                                       post.ctypes.data if post is not None else None, int(threads), C.byref(view))
+        if rc != 0:
+            raise ArachneError("arx_recbuf_build: " + self.lib.arx_recbuf_error(self.h).decode())
+        return view
+
+    def free(self):
+        if self.h:
+            self.lib.arx_recbuf_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def worth_running_rfa(barcode: str, n_pairs: int, unique: bool = True) -> bool:

@@ -248,10 +248,16 @@ template <class RT> struct Batch {
 		ARX_TRY(c, b->rt.bind(); b->pipe.fetch(b->db, b->work, reg_off, (arx::Reg *)regs, (arx::Aln *)alns, cigars);)                \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
-	int arx_batch_rfa(arx_ctx *h, arx_batch *bh, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int32_t penalty, \
+	int arx_batch_rfa(arx_ctx *h, arx_batch *bh, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, double penalty_f, \
 	                  const int64_t *cen_start, const int64_t *cen_end, int64_t *n_cands)                                           \
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!(penalty_f == (double)(int32_t)penalty_f) || penalty_f < -1000000.0 || penalty_f > 1000000.0) {                        \
+			c->set_error("improper-pair penalty (-i) must be an integer: placement scores are kept in exact half-units (penalty / 2 enters " \
+			             "fastScore, aligner.go:1140-1198), and a non-integer value would make the result depend on Go's float summation order"); \
+			return ARX_E_ARG;                                                                                                       \
+		}                                                                                                                           \
+		const int32_t penalty = (int32_t)penalty_f;                                                                                 \
 		if (!b->work.alns) { c->set_error("arx_batch_rfa before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }                 \
 		if (n_barcodes <= 0 || bc_pair_off[0] != 0 || 2 * bc_pair_off[n_barcodes] != b->db.n_reads) { c->set_error("barcode offsets must cover the batch"); return ARX_E_ARG; } \
 		for (int i = 0; i < n_barcodes; ++i) if (bc_pair_off[i + 1] < bc_pair_off[i]) { c->set_error("barcode offsets must not decrease"); return ARX_E_ARG; } \

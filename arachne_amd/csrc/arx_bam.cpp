@@ -1,6 +1,7 @@
 // arx_bam.cpp -- C ABI of the BAM sink (bam_sink.h); host code only.
 #include <stdio.h>
 #include "bam_sink.h"
+#include "bam_records.h"
 
 extern "C" {
 
@@ -47,5 +48,23 @@ int arx_bam_close(arx_bam *h, int64_t *stats)
 }
 
 const char *arx_bam_error(arx_bam *h) { return ((arx::BamSink *)h)->error.c_str(); }
+
+struct RecBufHandle { arx::RecBuf buf; std::string error; };
+int arx_recbuf_create(arx_recbuf **out)
+{
+	try { *out = (arx_recbuf *)new RecBufHandle(); } catch (const std::exception &) { *out = nullptr; return ARX_E_IO; }
+	return ARX_OK;
+}
+int arx_recbuf_build(arx_recbuf *h, const arx_super_batch *sb, const int32_t *cand_off, const arx_cand *cands, const arx_aln *alns, const uint32_t *cigars,
+                     const arx_cand_post *post, int32_t threads, arx_bam_batch *view)
+{
+	RecBufHandle *rb = (RecBufHandle *)h;
+	if (!sb || !cand_off || !cands || !alns || !cigars || !view) { rb->error = "null argument"; return ARX_E_ARG; }
+	try {
+		return rb->buf.build(*sb, cand_off, cands, alns, cigars, post, threads, view, rb->error) ? ARX_OK : ARX_E_ARG;
+	} catch (const std::exception &e) { rb->error = e.what(); return ARX_E_IO; }
+}
+const char *arx_recbuf_error(arx_recbuf *h) { return ((RecBufHandle *)h)->error.c_str(); }
+void arx_recbuf_free(arx_recbuf *h) { delete (RecBufHandle *)h; }
 
 }

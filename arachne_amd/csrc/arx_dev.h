@@ -38,9 +38,9 @@ constexpr int PES_LOW = -35, PES_HIGH = 500, MAX_RESCUE = 50;
 
 constexpr int MAX_READ_LEN = 249;   // u8 rescue SW is only exact below 250 (bwamem_pair.c:150)
 // Extensions are binned by query length so that a wavefront's four 16-lane groups run the same register tiling
-// (hip_sw_coop.h: C columns per lane, 16 * C > qlen)
-constexpr int EXT_CLASSES = 4;
-ARX_DEVI int ext_class(int qlen) { return qlen < 64 ? 0 : qlen < 112 ? 1 : qlen < 160 ? 2 : 3; }
+// (hip_sw_coop.h: C columns per lane, 16 * C > qlen; C = 2, 3, 4, 6, 8, 10, 16)
+constexpr int EXT_CLASSES = 7;
+ARX_DEVI int ext_class(int qlen) { return qlen < 32 ? 0 : qlen < 48 ? 1 : qlen < 64 ? 2 : qlen < 96 ? 3 : qlen < 128 ? 4 : qlen < 160 ? 5 : 6; }
 constexpr int CAP_INTV = 256;       // SMEM intervals kept per read (overflow is reported, never truncated silently)
 
 // error bits raised by kernels into Pipeline::d_err

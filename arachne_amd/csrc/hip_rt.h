@@ -476,10 +476,18 @@ struct HipRT {
 				Scope sc(*this, nm, nc);
 				const ExtTask *tk = f.tasks + (size_t)c * stride;
 				const int blocks = coop_blocks(nc);
-				if (c == 0) hipLaunchKernelGGL(k_extend_g16<4>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
-				else if (c == 1) hipLaunchKernelGGL(k_extend_g16<7>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
-				else if (c == 2) hipLaunchKernelGGL(k_extend_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
-				else hipLaunchKernelGGL(k_extend_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc);
+#define ARX_EXT_LAUNCH(CN, CO) do { if (ext_old) hipLaunchKernelGGL((k_extend_b16<CO, true>), dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc); \
+                                    else hipLaunchKernelGGL((k_extend_b16<CN, false>), dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, tk, f.res, nc); } while (0)
+				switch (c) {
+				case 0: ARX_EXT_LAUNCH(2, 4); break;
+				case 1: ARX_EXT_LAUNCH(3, 4); break;
+				case 2: ARX_EXT_LAUNCH(4, 4); break;
+				case 3: ARX_EXT_LAUNCH(6, 7); break;
+				case 4: ARX_EXT_LAUNCH(8, 10); break;
+				case 5: ARX_EXT_LAUNCH(10, 10); break;
+				default: ARX_EXT_LAUNCH(16, 16); break;
+				}
+#undef ARX_EXT_LAUNCH
 				ARX_HIP_CHECK(hipGetLastError());
 			}
 			return;
@@ -494,9 +502,11 @@ struct HipRT {
 			if (nb > 0 && (total + 3) / 4 > cap) { nb = (int)((int64_t)nb * cap / ((total + 3) / 4)); if (nb < 1) nb = 1; } // share the grid cap by class size
 			sh.nb[c] = nb; blocks += nb;
 		}
-		hipLaunchKernelGGL(k_extend_classes, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, stride, f.res, sh);
+		if (ext_old) hipLaunchKernelGGL(k_extend_classes_b<true>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, stride, f.res, sh);
+		else hipLaunchKernelGGL(k_extend_classes_b<false>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.tasks, stride, f.res, sh);
 		ARX_HIP_CHECK(hipGetLastError());
 	}
+	bool ext_old = getenv("ARX_EXT_OLD") && atoi(getenv("ARX_EXT_OLD")) != 0; // A/B: round 2's extension kernel (ext2_g16) on the same class lists
 	// CIGARs of the gapped regions: 16 lanes per region (hip_nw_coop.h); f is pipeline.h's KReg2Aln
 	template <class F> void run_reg2aln_nw(const char *nm, int n, const int32_t *n_class, const F &f, uint8_t *zbuf, const int32_t *z_off)
 	{

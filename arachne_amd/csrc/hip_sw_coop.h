@@ -19,28 +19,32 @@ namespace arx {
 // row keep `old`.
 constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_ROR = 0x120; // + shift amount 1..15
 template <int CTRL> __device__ __forceinline__ int dpp_row(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+// The same with zero fill (bound_ctrl:1, old = 0): in this form the compiler folds the lane movement into the instruction that uses the
+// value (v_max_i32_dpp, v_sub_u32_dpp, ...: one instruction), where the general form costs a move of `old`, a v_mov_b32_dpp and the
+// operation itself.  Rotations have no invalid source lane, so the fill never shows there.
+template <int CTRL> __device__ __forceinline__ int dpp_rowz(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 
 __device__ __forceinline__ int g16_shift_up(int v, int) // lane l of each 16-lane row receives lane l-1's value, lane 0 receives 0
 {
-	return dpp_row<DPP_ROW_SHR + 1>(0, v);
+	return dpp_rowz<DPP_ROW_SHR + 1>(v);
 }
 template <int N> __device__ __forceinline__ int g16_shift_up_n(int v, int fill) { return dpp_row<DPP_ROW_SHR + N>(fill, v); }
 __device__ __forceinline__ int g16_max(int v) // butterfly by row rotations: every lane ends up with the group maximum
 {
 	int t;
-	t = dpp_row<DPP_ROW_ROR + 8>(v, v); v = v > t ? v : t;
-	t = dpp_row<DPP_ROW_ROR + 4>(v, v); v = v > t ? v : t;
-	t = dpp_row<DPP_ROW_ROR + 2>(v, v); v = v > t ? v : t;
-	t = dpp_row<DPP_ROW_ROR + 1>(v, v); v = v > t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 8>(v); v = v > t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 4>(v); v = v > t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 2>(v); v = v > t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 1>(v); v = v > t ? v : t;
 	return v;
 }
 __device__ __forceinline__ int g16_min(int v)
 {
 	int t;
-	t = dpp_row<DPP_ROW_ROR + 8>(v, v); v = v < t ? v : t;
-	t = dpp_row<DPP_ROW_ROR + 4>(v, v); v = v < t ? v : t;
-	t = dpp_row<DPP_ROW_ROR + 2>(v, v); v = v < t ? v : t;
-	t = dpp_row<DPP_ROW_ROR + 1>(v, v); v = v < t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 8>(v); v = v < t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 4>(v); v = v < t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 2>(v); v = v < t ? v : t;
+	t = dpp_rowz<DPP_ROW_ROR + 1>(v); v = v < t ? v : t;
 	return v;
 }
 __device__ __forceinline__ bool g16_all(bool p)
@@ -468,41 +472,218 @@ __device__ ExtRes ext2_g16(const IndexView &ix, const uint8_t *bases, const ExtT
 	return r;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// ext2_b16 (round 3): the same recurrence and the same column layout as ext2_g16 (column j in lane j / C, register j % C), with the
+// band predicates taken out of the arithmetic -- 27 vector instructions per column instead of ~50:
+//  * left of the band.  beg only grows, so a column that has left the band on the left is never read again (ksw.c:411-412, 466-467).
+//    Such columns hold H = E = 0 here: the zero scan that moves beg only passes columns that are zero already, and the one column a row
+//    can lose to the band limit (beg = i - w) is zeroed when that happens.  A zero column computes zeros (M = 0, e = 0, its key t + k = k
+//    never lifts the F of a column inside the band above 0), hands H = 0 = h1 to column beg, and ranks below every live column in the
+//    row maximum: no "j >= beg" test anywhere; the row's first column gets h1 as the fill of the lane shift (only column 0 can need a
+//    non-zero one).
+//  * right of the band.  Columns beyond `end` keep their stale values as the reference's array does (they are read again when the
+//    band re-grows, ksw.c:468-469); they are computed like the others and only the write-back is masked: one compare for "j < end",
+//    one for "j == end" (eh[end] = {h1, 0}).  Their keys only reach prefixes of columns further right, i.e. columns that are masked too.
+//  * M = H ? H + s : 0 is min(H + s, H << 15): for H = 0 that is min(s, 0) <= 0, and a non-positive M acts exactly like 0 in
+//    everything that follows (h = max(M, e, f) with e, f >= 0; t = max(M - 7, 0)); the score s comes out of one nibble table per column.
+//  * positions inside a lane are compile-time constants (u), the lane's base column is added once per row where a reduction needs it;
+//    the zero scan is one bit per column, first / last set bit per lane, one packed 16-bit reduction for both.
+//  * dead-row bound as in ext2_g16, but a column with H == 0 (E == 0) contributes 0, not qlen - j: nothing follows from a zero.
+// Results are those of ext2_g16 / ext2_task bit for bit (ARX_EXT_OLD=1 runs the old kernel for comparison).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int g16_pkmax_u16(int v) // both 16-bit halves reduced at once
+{
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	auto pk = [](int a, int b) { us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b); us2 z = __builtin_elementwise_max(x, y); return __builtin_bit_cast(int, z); };
+	int t;
+	t = dpp_rowz<DPP_ROW_ROR + 8>(v); v = pk(v, t);
+	t = dpp_rowz<DPP_ROW_ROR + 4>(v); v = pk(v, t);
+	t = dpp_rowz<DPP_ROW_ROR + 2>(v); v = pk(v, t);
+	t = dpp_rowz<DPP_ROW_ROR + 1>(v); v = pk(v, t);
+	return v;
+}
+
 template <int C>
-__device__ __forceinline__ void extend_class_g16(const IndexView &ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n, int blk, int n_blk, uint8_t *tl)
+__device__ ExtRes ext2_b16(const IndexView &ix, const uint8_t *bases, const ExtTask &t, uint8_t *tl)
+{
+	const int l = __lane_id() & 15;
+	const int qlen = t.qlen, tlen = t.tlen, h0 = t.h0;
+	const int c0 = l * C;
+	const int NEG = -0x40000000;
+	int H[C], E[C], Mv[C], M7[C], hv[C], pref[C];
+	uint32_t SCW[C]; // nibble tb of SCW[u]: score of column c0 + u against target base tb, plus 4
+#pragma unroll
+	for (int u = 0; u < C; ++u) {
+		const int j = c0 + u;
+		int v = j == 0 ? h0 : h0 - 6 - j; // first row (ksw.c:395-397)
+		H[u] = v > 0 ? v : 0;
+		E[u] = 0;
+		const int q = j < qlen ? bases[t.qoff + j * t.qdir] : 4;
+		SCW[u] = q > 3 ? 0x3333u : (5u << (4 * q)); // match 1 + 4, mismatch -4 + 4, N -1 + 4 (the target never holds an N)
+	}
+	int w = t.w;
+	{
+		int mg = qlen + OPT_PEN_CLIP5 - 5; // max_ins == max_del (ksw.c:402-407)
+		mg = mg > 1 ? mg : 1;
+		w = w < mg ? w : mg;
+	}
+	const int n_stage = tlen < EXT_T_CAP ? tlen : EXT_T_CAP;
+	for (int k = l; k < n_stage; k += 16) tl[k] = (uint8_t)ref_base(ix, t.tpos + (int64_t)k * t.tdir);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	const int rq_lane = l == qlen / C ? qlen % C : -1; // the register that holds column qlen, in the lane that holds it
+	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+	for (int i = 0; i < tlen; ++i) {
+		const int tb4 = 4 * (i < EXT_T_CAP ? tl[i] : ref_base(ix, t.tpos + (int64_t)i * t.tdir));
+		if (beg < i - w) { // the band limit drops column i - w - 1 (at most one per row): columns left of the band hold zeros
+			const int dj = i - w - 1 - c0;
+#pragma unroll
+			for (int u = 0; u < C; ++u) { const bool z = dj == u; H[u] = z ? 0 : H[u]; E[u] = z ? 0 : E[u]; }
+			beg = i - w;
+		}
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1init = h0 - (OPT_O_DEL + OPT_E_DEL * (i + 1));
+		h1init = (beg == 0 && h1init > 0) ? h1init : 0;
+		const int nact = end - c0; // registers u < nact are inside the band, u == nact is column `end`
+		// sweep 1: M and the lane's running maximum of t(k) + k + 1 (k counted from the lane's first column; the + 1 makes every key
+		// positive, so that 0 is "no column yet" and the lane shifts of the scan can fill with zeros -- the form the compiler folds into
+		// the maximum, one instruction per step)
+		int pm = 0;
+#pragma unroll
+		for (int u = 0; u < C; ++u) {
+			const int sc4 = (int)((SCW[u] >> tb4) & 15u);
+			const int hs = H[u] + sc4 - 4, hz = H[u] << 15;
+			const int M = hs < hz ? hs : hz;
+			Mv[u] = M; M7[u] = M - 7;
+			pref[u] = pm;
+			int key = M7[u] + (u + 1); key = key > u + 1 ? key : u + 1;
+			pm = pm > key ? pm : key;
+		}
+		int x = pm + c0, y;
+		y = dpp_rowz<DPP_ROW_SHR + 1>(x); x = x > y ? x : y;
+		y = dpp_rowz<DPP_ROW_SHR + 2>(x); x = x > y ? x : y;
+		y = dpp_rowz<DPP_ROW_SHR + 4>(x); x = x > y ? x : y;
+		y = dpp_rowz<DPP_ROW_SHR + 8>(x); x = x > y ? x : y;
+		const int ex = dpp_rowz<DPP_ROW_SHR + 1>(x) - c0; // exclusive prefix maximum relative to this lane's first column: >= 0 (the lane before ends on a key >= its base + C), 0 in lane 0
+		// sweep 2: F, H, E; the lane's row maximum as (h << 8 | u)
+		int best = 0;
+#pragma unroll
+		for (int u = 0; u < C; ++u) {
+			const int pmx = ex > pref[u] ? ex : pref[u];
+			const int F = pmx - u; // (max of t(k) + k + 1) - 1 - (j - 1); 0 - u <= 0 where no column precedes: like the serial chain's f = 0 it never beats M, E >= 0
+			int h = Mv[u] > E[u] ? Mv[u] : E[u];
+			h = h > F ? h : F;
+			hv[u] = h;
+			int e = E[u] - 1; e = e > M7[u] ? e : M7[u]; e = e > 0 ? e : 0;
+			const bool act = nact > u;
+			E[u] = act ? e : E[u];
+			const int pk = (act ? h : 0) << 8 | u;
+			best = best > pk ? best : pk;
+		}
+		// sweep 3: eh[j].h <- H(i, j-1) for beg < j <= end, eh[end].e <- 0; one bit per column for the zero scan
+		const int h1lane = l == 0 ? h1init : 0;
+		int from_prev = dpp_rowz<DPP_ROW_SHR + 1>(hv[C - 1]);
+		from_prev = from_prev > h1lane ? from_prev : h1lane; // lane 0 (column 0): h1; scores are >= 0
+		uint32_t zm = 0;
+		int own = -1;
+#pragma unroll
+		for (int u = 0; u < C; ++u) {
+			const int prev = u == 0 ? from_prev : hv[u > 0 ? u - 1 : 0];
+			const int hn = nact >= u ? prev : H[u];
+			H[u] = hn;
+			const int en = nact == u ? 0 : E[u];
+			E[u] = en;
+			const uint32_t nz = (uint32_t)(hn | en);
+			zm |= (nz < 1u ? nz : 1u) << u;
+			own = rq_lane == u ? hn : own;
+		}
+		const int packed = g16_max(best + c0);
+		const int m = packed >> 8, mj = packed & 0xff;
+		if (end == qlen) { // column qlen now holds H(i, qlen - 1), or h1 after an empty row
+			const int h1 = g16_max(own);
+			max_ie = gscore > h1 ? max_ie : i;
+			gscore = gscore > h1 ? gscore : h1;
+		}
+		if (m == 0) break;
+		if (m > max) {
+			max = m; max_i = i; max_j = mj;
+			int off = mj - i; off = off < 0 ? -off : off;
+			max_off = max_off > off ? max_off : off;
+		} else {
+			if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * OPT_E_DEL > OPT_ZDROP) break; }
+			else { if (max - m - ((mj - max_j) - (i - max_i)) * OPT_E_INS > OPT_ZDROP) break; }
+		}
+		// adaptive band (ksw.c:466-469): first non-zero column of [beg, end), last non-zero column of [beg', end]
+		{
+			int nk = nact + 1; nk = nk < 0 ? 0 : (nk > C ? C : nk);
+			int ne = nact < 0 ? 0 : (nact > C ? C : nact);
+			const uint32_t zk = zm & ((1u << nk) - 1u), ze = zm & ((1u << ne) - 1u);
+			const int lo = ze ? c0 + __builtin_ctz(ze) : 1023, hi = zk ? c0 + 32 - __builtin_clz(zk) : 0; // hi = last column + 1
+			const int red = g16_pkmax_u16((1023 - lo) << 16 | hi);
+			const int first = 1023 - (int)((uint32_t)red >> 16);
+			int last = (red & 0xffff) - 1;
+			const int nbeg = first < end ? first : end;
+			if (last < nbeg) last = nbeg - 1;
+			beg = nbeg;
+			end = last + 2 < qlen ? last + 2 : qlen;
+		}
+		// rows that can no longer matter (see ext2_g16); a zero H or E starts nothing
+		if ((i & ARX_EXT_CHECK_MASK) == ARX_EXT_CHECK_MASK && m < max && gscore >= 0) {
+			int bound = beg == 0 ? h0 - (OPT_O_DEL + OPT_E_DEL * (i + 2)) + qlen : -1;
+			const int rem = qlen - c0;
+#pragma unroll
+			for (int u = 0; u < C; ++u) {
+				const int a = H[u] ? H[u] + (rem - u) : 0, b = E[u] ? E[u] + (rem - 1 - u) : 0;
+				const int xx = rem - u >= 0 ? (a > b ? a : b) : -1;
+				bound = bound > xx ? bound : xx;
+			}
+			bound = g16_max(bound);
+			if (bound < max && bound < gscore) break;
+		}
+	}
+	ExtRes r;
+	r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	return r;
+}
+
+// (Handing a workgroup 16 or 64 extensions at a time, sorted by query length so that the four groups of a wavefront run rows of similar
+// count in lockstep, was measured in round 3: no gain at 16, twice the time at 64 -- the kernel is not bound by the idle lanes of a
+// finished group.  Extensions are taken four at a time in queue order.)
+template <int C, bool OLD>
+__device__ __forceinline__ void extend_class_b16(const IndexView &ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n, int blk, int n_blk, uint8_t *tl)
 {
 	const int g = threadIdx.x >> 4;
 	for (int i = blk * 4 + g; i < n; i += n_blk * 4) {
 		const ExtTask t = tasks[i];
-		ExtRes r = ext2_g16<C>(ix, bases, t, tl);
+		ExtRes r = OLD ? ext2_g16<C>(ix, bases, t, tl) : ext2_b16<C>(ix, bases, t, tl);
 		if ((threadIdx.x & 15) == 0) res[t.owner] = r;
 		__builtin_amdgcn_wave_barrier(); // the LDS row is reused by the group's next extension
 	}
 }
 
-template <int C>
-__global__ void __launch_bounds__(64) k_extend_g16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
+template <int C, bool OLD>
+__global__ void __launch_bounds__(64) k_extend_b16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
 {
 	__shared__ uint8_t target_lds[4][EXT_T_CAP];
-	extend_class_g16<C>(ix, bases, tasks, res, n, blockIdx.x, gridDim.x, target_lds[threadIdx.x >> 4]);
+	extend_class_b16<C, OLD>(ix, bases, tasks, res, n, blockIdx.x, gridDim.x, target_lds[threadIdx.x >> 4]);
 }
 
-// All query-length classes of a round in one launch: blocks [0, nb.x) take class 0, the next nb.y class 1, ...  Every
-// wavefront runs one tiling, and the classes run side by side (late rounds hold few extensions: launched one class after
-// the other, each launch would cost the latency of a whole DP).
+// All query-length classes of a round in one launch: blocks [0, nb[0]) take class 0, the next nb[1] class 1, ...  Every wavefront
+// runs one tiling, and the classes run side by side (late rounds hold few extensions: launched one class after the other, each launch
+// would cost the latency of a whole DP).
 struct ExtClassShape { int n[EXT_CLASSES], nb[EXT_CLASSES]; };
-static __global__ void __launch_bounds__(64) k_extend_classes(IndexView ix, const uint8_t *bases, const ExtTask *tasks, int stride, ExtRes *res, ExtClassShape sh)
+template <bool OLD>
+__global__ void __launch_bounds__(64) k_extend_classes_b(IndexView ix, const uint8_t *bases, const ExtTask *tasks, int stride, ExtRes *res, ExtClassShape sh)
 {
 	__shared__ uint8_t target_lds[4][EXT_T_CAP];
 	uint8_t *tl = target_lds[threadIdx.x >> 4];
 	int b = blockIdx.x;
-	if (b < sh.nb[0]) { extend_class_g16<4>(ix, bases, tasks, res, sh.n[0], b, sh.nb[0], tl); return; }
-	b -= sh.nb[0];
-	if (b < sh.nb[1]) { extend_class_g16<7>(ix, bases, tasks + (size_t)stride, res, sh.n[1], b, sh.nb[1], tl); return; }
-	b -= sh.nb[1];
-	if (b < sh.nb[2]) { extend_class_g16<10>(ix, bases, tasks + (size_t)2 * stride, res, sh.n[2], b, sh.nb[2], tl); return; }
-	b -= sh.nb[2];
-	extend_class_g16<16>(ix, bases, tasks + (size_t)3 * stride, res, sh.n[3], b, sh.nb[3], tl);
+#define ARX_EXT_CASE(c, CN, CO) if (b < sh.nb[c]) { extend_class_b16<OLD ? CO : CN, OLD>(ix, bases, tasks + (size_t)(c) * stride, res, sh.n[c], b, sh.nb[c], tl); return; } b -= sh.nb[c];
+	ARX_EXT_CASE(0, 2, 4) ARX_EXT_CASE(1, 3, 4) ARX_EXT_CASE(2, 4, 4) ARX_EXT_CASE(3, 6, 7) ARX_EXT_CASE(4, 8, 10) ARX_EXT_CASE(5, 10, 10)
+	extend_class_b16<16, OLD>(ix, bases, tasks + (size_t)6 * stride, res, sh.n[6], b, sh.nb[6], tl);
+#undef ARX_EXT_CASE
 }
 
 } // namespace arx

@@ -229,13 +229,30 @@ struct KExtStep {
 		const ExtRes rs = res[gid]; // only read by a chain that queued a DP in the previous round
 		const int what = ext_step(ix, gid, base_off[r], lens[r], chains + g0, gid - c0, seeds, srt, regs, state + c0, round, st, rs, t);
 		state[gid] = st;
+#if defined(__HIP_DEVICE_COMPILE__)
+		// One atomic round trip per wavefront: the lanes count themselves per list with ballots, the first lane of every list reserves for
+		// all of them (its own class list and the list of chains still active: two atomics in flight together), the others read the base
+		// from it.  (One counter after the other -- seven classes since round 3 -- put seven dependent round trips into every wavefront.)
+		const int c = what == EXT_TASK ? ext_class(t.qlen) : -1;
+		const bool keep = what != EXT_FINISHED;
+		const unsigned long long m_keep = __ballot(keep), lt = (1ull << __lane_id()) - 1ull;
+		unsigned long long m_c = 0;
+#pragma unroll
+		for (int k = 0; k < EXT_CLASSES; ++k) { const unsigned long long mk = __ballot(c == k); m_c = c == k ? mk : m_c; }
+		const int lead_c = c >= 0 ? __builtin_ctzll(m_c) : (int)__lane_id(), lead_k = keep ? __builtin_ctzll(m_keep) : (int)__lane_id();
+		int base_c = 0, base_k = 0;
+		if (c >= 0 && (int)__lane_id() == lead_c) base_c = atomicAdd(n_tasks + c, __popcll(m_c));
+		if (keep && (int)__lane_id() == lead_k) base_k = atomicAdd(n_tasks + EXT_CLASSES, __popcll(m_keep));
+		base_c = __shfl(base_c, lead_c); base_k = __shfl(base_k, lead_k);
+		if (c >= 0) tasks[(size_t)c * task_stride + base_c + __popcll(m_c & lt)] = t;
+		if (keep) act_out[base_k + __popcll(m_keep & lt)] = gid;
+#else
 		if (what == EXT_TASK) {
 			const int c = ext_class(t.qlen);
-			int at = 0;
-			for (int k = 0; k < EXT_CLASSES; ++k) if (c == k) at = claim(n_tasks + k); // one counter per branch: the compiler folds a wavefront's increments of one address into a single atomic
-			tasks[(size_t)c * task_stride + at] = t;
+			tasks[(size_t)c * task_stride + claim(n_tasks + c)] = t;
 		}
 		if (what != EXT_FINISHED) act_out[claim(n_tasks + EXT_CLASSES)] = gid;
+#endif
 	}
 	static ARX_DEVI int claim(int32_t *ctr) { return ARX_ATOMIC_INC(ctr); }
 };

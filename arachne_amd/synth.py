@@ -338,3 +338,36 @@ def write_fastq(rs: ReadSet, path1: str, path2: str) -> None:
                 L = int(rs.lens[row])
                 s = BASES[rs.seqs[row, :L]].tobytes().decode()
                 f.write(f"@r{i}/{mate}\tBX:Z:{bcs}\tVX:i:{vx}\n{s}\n+\n{'I' * L}\n")
+
+
+def write_fastq_fast(rs: ReadSet, path1: str, path2: str, p0: int = 0, p1: int = None) -> None:
+    """write_fastq for millions of pairs: pairs [p0, p1) of the set as two barcode-sorted FASTQ files, records laid out as rows of
+    one byte matrix per barcode-string length (same header format: '@r<pair, 9 digits>/<mate>\\tBX:Z:<bc>\\tVX:i:<0|1>'); reads must all
+    have the same length."""
+    p1 = rs.n_pairs if p1 is None else p1
+    n = p1 - p0
+    L = int(rs.lens[0])
+    assert (rs.lens[2 * p0:2 * p1] == L).all()
+    bc_bytes = [b.encode() for b in rs.barcodes]
+    bl = np.array([len(b) for b in bc_bytes])
+    ids = np.arange(p0, p1)
+    digits = ((ids[:, None] // 10 ** np.arange(8, -1, -1)[None, :]) % 10 + 48).astype(np.uint8)
+    bid = rs.barcode_id[p0:p1]
+    with open(path1, "wb") as f1, open(path2, "wb") as f2:
+        # consecutive pairs with the same barcode-string length form one block (all of them, when the barcodes are of one length)
+        cut = np.flatnonzero(np.diff(bl[bid])) + 1
+        bounds = np.concatenate([[0], cut, [n]])
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            k = int(bl[bid[a]])
+            hl = 1 + 1 + 9 + 2 + 6 + k + 6 + 1 + 1               # @ r digits /m \tBX:Z: bc \tVX:i: v \n
+            rec = hl + L + 1 + 2 + L + 1
+            bcm = np.frombuffer(b"".join(bc_bytes[i] for i in bid[a:b]), dtype=np.uint8).reshape(b - a, k)
+            for f, mate in ((f1, 0), (f2, 1)):
+                m = np.empty((b - a, rec), dtype=np.uint8)
+                m[:, 0] = 64; m[:, 1] = 114; m[:, 2:11] = digits[a:b]; m[:, 11] = 47; m[:, 12] = 49 + mate
+                m[:, 13:19] = np.frombuffer(b"\tBX:Z:", dtype=np.uint8); m[:, 19:19 + k] = bcm
+                m[:, 19 + k:25 + k] = np.frombuffer(b"\tVX:i:", dtype=np.uint8); m[:, 25 + k] = 48 + rs.valid[p0 + a:p0 + b]; m[:, 26 + k] = 10
+                m[:, hl:hl + L] = BASES[rs.seqs[2 * (p0 + a) + mate:2 * (p0 + b):2, :L]]
+                m[:, hl + L] = 10; m[:, hl + L + 1] = 43; m[:, hl + L + 2] = 10
+                m[:, hl + L + 3:hl + 2 * L + 3] = 73; m[:, rec - 1] = 10
+                f.write(m.tobytes())

@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--scatter-steps", type=int, default=0, help="N > 1: extra steps run as SURVEY.md s8e's dataflow -- rank 0 owns every rank's barcodes, assigns whole "
                     "barcodes by pair count (LPT), scatters the packed batches and gathers the result slabs over torch.distributed point-to-point (RCCL / xGMI) "
                     "inside the timed steps; reported under `scatter_gather` (an ingest rank cannot feed 8 GPUs at kernel rate: see DESIGN.md s6)")
+    ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false", help="skip the FASTQ -> BAM pass (reported under `end_to_end`, never as `value`)")
+    ap.add_argument("--e2e-workers", type=int, default=6, help="file pairs / worker threads of the end-to-end pass")
     ap.add_argument("--depth", type=int, default=1, help="batch handles per chunk of the read set (steps in flight)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
@@ -708,6 +710,40 @@ def main():
                     out["parity_ok"] = False
                     out["parity_error"] = str(e)[:500]
                     parity_failed = str(e)
+        # End to end (SURVEY.md s8d "reported separately"): the same read set as barcode-sorted FASTQ files on disk -> arx_feeder -> the path ->
+        # arx_recbuf (AppendBam's record logic) -> arx_bam (BGZF), the loop of Arachne() (aligner.go:335-371, bamwriter.go:615-658) as
+        # arachne_amd/e2e.py drives it through the C ABI; one worker thread per file pair.  Never `value`.
+        if args.end_to_end and world == 1 and not args.no_rfa:
+            try:
+                from arachne_amd import e2e
+                import shutil
+                ed = os.path.join(args.cache, "e2e_%d" % os.getpid())
+                os.makedirs(ed, exist_ok=True)
+                t = time.time()
+                k = max(1, args.e2e_workers)
+                cuts = [int(po[(len(po) - 1) * i // k]) for i in range(k)] + [rs.n_pairs]
+                files = []
+                for i in range(k):
+                    f1, f2 = os.path.join(ed, "r1_%d.fq" % i), os.path.join(ed, "r2_%d.fq" % i)
+                    synth.write_fastq_fast(rs, f1, f2, cuts[i], cuts[i + 1])
+                    files.append((f1, f2))
+                t_w = time.time() - t
+                for bs in sets:                      # the resident batches give their memory back to the end-to-end workers' handles
+                    for b in bs:
+                        b.free()
+                sets, batches = [], []
+                st = e2e.run(ref, files, os.path.join(ed, "out"), pairs_per_batch=max(20000, rs.n_pairs // (3 * k)), bam_threads=8, rec_threads=8,
+                             lib_path=args.lib or api.LIB_PATH)
+                out["end_to_end"] = dict(value=st["pairs_per_s"], unit="paired reads/s", pairs=st["pairs"], seconds=round(st["seconds"], 3), workers=k,
+                                         fastq_bytes=sum(os.path.getsize(f) for pr in files for f in pr), bam_bytes=st.get("bam_bytes"), fastq_write_s=round(t_w, 2),
+                                         worker_seconds={kk: round(st[kk], 3) for kk in ("feeder_s", "device_s", "fetch_s", "records_s", "bam_s")},
+                                         note="FASTQ files on disk (plain, barcode-sorted, one pair per worker) -> arx_feeder_next -> arx_batch_reset/run/rfa/post -> "
+                                              "arx_batch_fetch + rfa_fetch + post_fetch -> arx_recbuf_build (primary record per read) -> arx_bam_write (BGZF level 1, one BAM per "
+                                              "worker); wall clock over all workers; worker_seconds are summed over the workers")
+                shutil.rmtree(ed, ignore_errors=True)
+            except Exception as e:  # the headline number does not depend on this pass
+                log("end-to-end pass failed:", repr(e))
+                out["end_to_end"] = dict(error=repr(e)[:300])
         print(json.dumps(out), flush=True)
     for bs in sets:
         for b in bs:

@@ -93,8 +93,10 @@ typedef struct {
 	int32_t active, is_proper, mapq, molecule_id, active_molecule, in_filtered /* score >= best - 17 */, best_in_mol, pad;
 } arx_cand;
 /* bc_pair_off[n_barcodes+1]: pair offsets of the (whole) barcodes in the batch; do_rfa[b]: worthRunningRFA (aligner.go:1018-1030),
- * decided by the caller from the barcode string; penalty: -i (integer, default -4); cen_start/cen_end per contig or NULL. */
-int arx_batch_rfa(arx_ctx *ctx, arx_batch *b, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, int32_t penalty,
+ * decided by the caller from the barcode string; penalty: the reference's -i flag (a float64, main.go:28; default -4).  Only integer
+ * values are accepted (ARX_E_ARG with a message otherwise): every score term is then a multiple of 0.5 and the sums are exact in any
+ * order, which is what makes the result well defined; cen_start/cen_end per contig or NULL. */
+int arx_batch_rfa(arx_ctx *ctx, arx_batch *b, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa, double penalty,
                   const int64_t *cen_start, const int64_t *cen_end, int64_t *n_cands);
 int arx_batch_rfa_fetch(arx_ctx *ctx, arx_batch *b, int32_t *cand_off /* n_reads+1 */, arx_cand *cands /* n_cands */);
 
@@ -172,6 +174,19 @@ int arx_bam_write(arx_bam *w, const arx_bam_batch *batch);
 /* stats[4] (may be NULL): records, BGZF blocks, uncompressed bytes, file bytes */
 int arx_bam_close(arx_bam *w, int64_t *stats);
 const char *arx_bam_error(arx_bam *w);
+
+/* ---- between the path and the sink: the placed candidate of every read of a super-batch as BAM records -- the part of DumpToBams /
+ * AppendBam (src/aligner/bamwriter.go:283-568, 635-658) that decides flags, position, MAPQ, mate fields, template length, CIGAR op codes,
+ * strand of bases and qualities and the RG / AS / XM / AM / XT / BX / VX tags of the primary record (csrc/bam_records.h lists what is left
+ * to the caller: split records and their tags).  sb: the super-batch the batch was created from; cand_off / cands: arx_batch_rfa_fetch;
+ * alns / cigars: arx_batch_fetch; post: arx_batch_post_fetch's per-candidate records or NULL (no duplicate flags).  The view points
+ * into the buffer and stays valid until the next build on it; hand it to arx_bam_write.  Host code only. */
+typedef struct arx_recbuf arx_recbuf;
+int arx_recbuf_create(arx_recbuf **out);
+int arx_recbuf_build(arx_recbuf *rb, const arx_super_batch *sb, const int32_t *cand_off, const arx_cand *cands, const arx_aln *alns, const uint32_t *cigars,
+                     const arx_cand_post *post, int32_t threads, arx_bam_batch *view);
+const char *arx_recbuf_error(arx_recbuf *rb);
+void arx_recbuf_free(arx_recbuf *rb);
 
 /* intermediate results for parity tests (device -> host copies of stage outputs) */
 #define ARX_CAP_INTV 256

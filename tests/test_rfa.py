@@ -209,3 +209,26 @@ def test_gpu_matches_restatement(seed, guard, monkeypatch):
     if guard:
         monkeypatch.setenv("ARX_MAPQ_GUARD", guard)
     _device_vs_oracle(api.LIB_PATH, seed)
+
+
+def test_non_integer_penalty_is_rejected_with_a_message_hostsim():
+    """The reference's -i flag is a float64 (main.go:28); the path keeps scores in exact half-units, so arx_batch_rfa takes the value as
+    a double and refuses a non-integer one (ARX_E_ARG + message) instead of rounding it silently; integers given as floats pass."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    g = synth.make_genome(5, [200000])
+    rs = synth.make_reads(6, g, 1, 12)
+    d = tempfile.mkdtemp(prefix="arx_pen_")
+    fa = os.path.join(d, "g.fa")
+    g.write_fasta(fa)
+    api.index_build(fa, fa, lib_path=SIM)
+    ref = api.Reference(fa, lib_path=SIM)
+    b = ref.batch(rs.seqs, rs.lens).run()
+    with pytest.raises(api.ArachneError, match="must be an integer"):
+        b.rfa([0, 12], [True], penalty=-4.5)
+    with pytest.raises(api.ArachneError, match="must be an integer"):
+        b.rfa([0, 12], [True], penalty=float("nan"))
+    a = b.rfa([0, 12], [True], penalty=-4.0)
+    c = b.rfa([0, 12], [True], penalty=-4)
+    assert a["cands"].tobytes() == c["cands"].tobytes()
+    b.free()
+    ref.close()
