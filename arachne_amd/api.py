@@ -69,6 +69,8 @@ def _load(path):
     lib.arx_contigs.argtypes = [vp] + [vp] * 6
     lib.arx_batch_create.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
     lib.arx_batch_reset.argtypes = [vp, vp, i32, vp, vp]
+    lib.arx_batch_reset_device.argtypes = [vp, vp, i32, i64, vp, vp]
+    lib.arx_batch_device_view.argtypes = [vp, vp, vp]
     lib.arx_batch_run.argtypes = [vp, vp, i32]
     lib.arx_batch_counts.argtypes = [vp, vp, vp]
     lib.arx_batch_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -117,6 +119,11 @@ def index_build(fasta: str, prefix: str, lib_path: str = LIB_PATH) -> None:
         raise ArachneError("arx_index_build: " + msg.value.decode())
 
 
+class _DeviceView(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_regs", C.c_int64), ("n_cigar", C.c_int64), ("n_cands", C.c_int64), ("reg_off", C.c_void_p), ("regs", C.c_void_p),
+                ("alns", C.c_void_p), ("cigars", C.c_void_p), ("cand_off", C.c_void_p), ("cands", C.c_void_p)]
+
+
 class Batch:
     """One batch of read pairs resident on the device (arx_batch)."""
 
@@ -143,6 +150,25 @@ class Batch:
         self._n_cands = 0
         self.ref._check(self.ref.lib.arx_batch_reset(self.ref.h, self.h, self.n_reads, bases.ctypes.data, lens.ctypes.data))
         return self
+
+    def reset_device(self, n_reads: int, n_bases: int, d_bases: int, d_lens: int):
+        """arx_batch_reset_device: new reads from DEVICE pointers (e.g. a tensor received over RCCL); the caller's stream must be done with them."""
+        self.n_reads = int(n_reads)
+        self._keep = None
+        self._n_cands = 0
+        self.ref._check(self.ref.lib.arx_batch_reset_device(self.ref.h, self.h, int(n_reads), int(n_bases), C.c_void_p(d_bases), C.c_void_p(d_lens)))
+        return self
+
+    def device_view(self):
+        """arx_batch_device_view -> dict name -> (device pointer, element count, numpy dtype) of the dense result arrays where they lie"""
+        v = _DeviceView()
+        self.ref._check(self.ref.lib.arx_batch_device_view(self.ref.h, self.h, C.byref(v)))
+        out = dict(reg_off=(v.reg_off, v.n_reads + 1, np.dtype(np.int32)), regs=(v.regs, v.n_regs, REG_DTYPE), alns=(v.alns, v.n_regs, ALN_DTYPE),
+                   cigars=(v.cigars, v.n_cigar, np.dtype(np.uint32)))
+        if v.cands:
+            out["cand_off"] = (v.cand_off, v.n_reads + 1, np.dtype(np.int32))
+            out["cands"] = (v.cands, v.n_cands, CAND_DTYPE)
+        return out
 
     def fetch_into(self, buf):
         """arx_batch_fetch + arx_batch_rfa_fetch into arrays the caller keeps (buf: dict with reg_off, regs, alns, cigars, cand_off, cands,

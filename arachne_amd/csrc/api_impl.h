@@ -30,6 +30,22 @@ struct KSaDense {
 	ARX_DEV void operator()(int i, int) const { out[i] = sa_lookup(ix, (uint64_t)i * (uint64_t)d); }
 };
 
+// k-mer table (dev_fm.h: ktab_*): level d + 1 from level d, one thread per parent; the child of base b is the forward extension by b
+struct KKmerLevel {
+	IndexView ix; const uint64_t *in; uint64_t *out; int d; // in: 4^d entries (null: d == 0, the parents are the four single bases)
+	ARX_DEV void operator()(int p, int) const
+	{
+		if (d == 0) { uint64_t w[2]; ktab_pack(set_intv(ix, p), w); out[2 * (size_t)p] = w[0]; out[2 * (size_t)p + 1] = w[1]; return; }
+		const Biv ik = ktab_unpack(in[2 * (size_t)p], in[2 * (size_t)p + 1]);
+		for (int b = 0; b < 4; ++b) {
+			const Biv ok = extend1(ix, ik, 0, 3 - b);
+			uint64_t w[2]; ktab_pack(ok, w);
+			const size_t c = (size_t)p | (size_t)b << (2 * d);
+			out[2 * c] = w[0]; out[2 * c + 1] = w[1];
+		}
+	}
+};
+
 struct KOccRepack { // BWA's block layout -> the checkpointed one (dev_fm.h), one thread per 64-byte block
 	uint32_t *bwt;
 	ARX_DEV void operator()(int i, int) const { occ_repack_block(bwt + (size_t)i * 16); }
@@ -90,6 +106,31 @@ template <class RT> struct Context {
 				void *old = (void *)ix.sa;
 				for (auto &p : dev_index) if (p == old) { rt.pfree(p); p = dense; }
 				ix.sa = dense; ix.sa_intv = d;
+			}
+		}
+		{ // k-mer table for the third seeding pass (dev_fm.h): K from the genome size -- the largest K with 4^K <= symbols, at most 16 (GRCh38:
+		  // 16, 4.3 G entries = 69 GB of the 288 GB; measured at GRCh38 size: the pass takes 9.7 ms per step without a table, 5.6 at K = 12,
+		  // 4.2 at 14, 3.3 at 16) -- and never more than a third of the device memory that is free; ARX_KMER_K overrides, 0 = no table
+			const char *e = getenv("ARX_KMER_K");
+			int K = 0;
+			if (e) K = atoi(e);
+			else { while (K < 16 && ((uint64_t)1 << (2 * (K + 1))) <= ix.seq_len) ++K; }
+			if (K > OPT_MIN_SEED_LEN - 3) K = OPT_MIN_SEED_LEN - 3;
+			while (K >= 4 && ((uint64_t)20 << (2 * K)) > rt.free_bytes() / 3) --K; // 16 bytes per entry, plus the level before it while it is built
+			ix.ktab = nullptr; ix.ktab_k = 0;
+			if (K >= 4) {
+				uint64_t *prev = nullptr;
+				for (int d = 0; d < K; ++d) { // level d + 1: 4^(d+1) entries
+					const size_t n_out = (size_t)1 << (2 * (d + 1));
+					uint64_t *out = rt.template palloc<uint64_t>(2 * n_out + 2);
+					KKmerLevel kk{ix, prev, out, d};
+					rt.launch_wide("kmer_level", d == 0 ? 4 : (int)(n_out >> 2), kk);
+					rt.sync();
+					if (prev) rt.pfree(prev);
+					prev = out;
+				}
+				dev_index.push_back(prev);
+				ix.ktab = prev; ix.ktab_k = K;
 			}
 		}
 		for (auto &n : hix.names) name_ptrs.push_back(n.c_str());
@@ -204,6 +245,30 @@ template <class RT> struct Batch {
 			b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; b->rfa_marked = false;                      \
 			b->rfa = arx::RfaResult(); b->post = arx::PostResult();                                                                 \
 			b->pipe.upload_into(b->db, bases, lens, n_reads); b->lens_host.assign(lens, lens + n_reads);)                           \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_reset_device(arx_ctx *h, arx_batch *bh, int32_t n_reads, int64_t n_bases, const uint8_t *d_bases, const int32_t *d_lens) \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
+		if (n_bases < 0 || n_bases >= ((int64_t)1 << 31) - 64) { c->set_error("batch too large: more than 2^31 bases, split the batch"); return ARX_E_TOO_LARGE; } \
+		bool ok = false;                                                                                                            \
+		ARX_TRY(c, b->rt.bind();                                                                                                    \
+			b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; b->rfa_marked = false;                      \
+			b->rfa = arx::RfaResult(); b->post = arx::PostResult();                                                                 \
+			ok = b->pipe.upload_from_device(b->db, d_bases, d_lens, n_reads, n_bases, 0, b->lens_host);)                            \
+		if (!ok) { c->set_error("device batch: the read lengths do not add up to n_bases, or a length is outside [0, 249]"); return ARX_E_ARG; } \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_device_view(arx_ctx *h, arx_batch *bh, arx_device_view *v)                                                        \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.alns) { c->set_error("arx_batch_device_view before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }         \
+		ARX_TRY(c, b->rt.bind(); b->rt.sync();)                                                                                     \
+		v->n_reads = b->db.n_reads; v->n_regs = b->work.c_n_regs; v->n_cigar = b->work.c_n_cig;                                     \
+		v->reg_off = b->work.c_reg_off; v->regs = (const arx_reg *)b->work.c_regs; v->alns = (const arx_aln *)b->work.c_alns; v->cigars = b->work.c_cig; \
+		const bool placed = b->rfa_marked && !b->rfa.cand_off.empty();                                                              \
+		v->n_cands = placed ? b->rfa.n_cands : 0; v->cand_off = placed ? b->rfa.d_cand_off : nullptr; v->cands = placed ? (const arx_cand *)b->rfa.d_cands : nullptr; \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_run(arx_ctx *h, arx_batch *bh, int32_t last_stage)                                                                \

@@ -22,18 +22,29 @@ static void wsort_report(hipStream_t, const char *) {}
 namespace arx {
 // One heavy pair per 64-lane workgroup: the lanes copy both region lists into LDS, the wavefront replays the rescue state machine on
 // them (w_rescue_step of dev_regs_wave.h; wave = 0: lane 0 alone runs rescue_step(), kept for A/B runs), the lanes copy the lists back.  The scratch lists of the general dedup pass (ptmp, pidx) stay in HBM.
-static __global__ void __launch_bounds__(64) k_rescue_heavy(KRescueStep f, const int32_t *list, int n, int wave)
+// Launched once per LDS footprint (cap_lo < capacity of both lists <= cap_hi records of dynamic LDS): a pair of 60 + 60 regions takes 15 KB
+// where the longest ones take 58 KB, and the workgroups a CU holds -- two at the largest footprint -- are what this latency-bound kernel
+// scales with.  A launch walks the whole list through its own cursor and skips the other launches' pairs.
+static __global__ void __launch_bounds__(64) k_rescue_heavy(KRescueStep f, const int32_t *list, int n, int wave, int cap_lo, int cap_hi, int32_t *cursor)
 {
-	__shared__ Reg lds_regs[RESCUE_LDS_REGS];
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_rescue[];
+	Reg *lds_regs = (Reg *)lds_rescue;
 	__shared__ int new_n[2];
 	__shared__ WaveScratch ws;
+	__shared__ int next_h;
 	const int lane = threadIdx.x;
-	for (int h = blockIdx.x; h < n; h += gridDim.x) {
+	for (;;) {
+		if (lane == 0) next_h = atomicAdd(cursor, 1);
+		__syncthreads();
+		const int h = next_h;
+		__syncthreads();
+		if (h >= n) break; // every workgroup reaches this: the cursor only grows
 		const int p = list[h];
 		ResState st = f.state[p];
 		if (st.phase == 2) continue; // uniform
 		const int o0 = f.preg_off[2 * p], o1 = f.preg_off[2 * p + 1], o2 = f.preg_off[2 * p + 2];
 		const int c0 = o1 - o0, c1 = o2 - o1; // capacities (KPairCap); c0 + c1 <= RESCUE_LDS_REGS by construction of the list
+		if (c0 + c1 <= cap_lo || c0 + c1 > cap_hi) continue; // another launch's pair
 		const int n0 = f.n_regs[2 * p], n1 = f.n_regs[2 * p + 1];
 		{ // in: the live entries of both lists, word by word
 			const uint32_t *s0 = (const uint32_t *)(f.pregs + o0), *s1 = (const uint32_t *)(f.pregs + o1);
@@ -84,10 +95,22 @@ template <> void HipRT::run_rescue_heavy<KRescueStep>(const char *nm, int n, con
 {
 	if (n <= 0) return;
 	static const int wave = getenv("ARX_RESCUE_WAVE") ? atoi(getenv("ARX_RESCUE_WAVE")) : 1;
-	const int blocks = n < n_cu * 8 ? n : n_cu * 8;
+	// 1: three launches by LDS footprint (170 / 340 / 680 records: 5 / 3 / 2 workgroups per CU).  Measured in round 3: slower (36 -> 43 ms per step
+	// alone on the repeat-rich workload, 14 -> 18 on the default one) -- the launches of one stream run one after the other and each ends on
+	// its own longest pair; what bounds this kernel is the serial depth of its longest pairs, not the workgroups a CU holds.  Default: one launch.
+	static const int split = getenv("ARX_RESCUE_LDS_CLASSES") ? atoi(getenv("ARX_RESCUE_LDS_CLASSES")) : 0;
+	if (!rescue_heavy_attr_set) { ARX_HIP_CHECK(hipFuncSetAttribute((const void *)k_rescue_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RESCUE_LDS_REGS * sizeof(Reg)))); rescue_heavy_attr_set = true; }
+	int32_t *cur = alloc<int32_t>(4);
+	memset0(cur, 16);
 	on_aux([&]() { // beside the thread-per-pair launch of the same round (the caller joins before it reads the round's task count)
 		Scope sc(*this, nm, n);
-		hipLaunchKernelGGL(k_rescue_heavy, dim3(blocks), dim3(64), 0, stream, f, list, n, wave);
+		// footprints: 170 / 340 / 680 records = 15 / 30 / 60 KB of dynamic LDS beside the 17 KB of sort scratch: 5 / 3 / 2 workgroups per CU
+		const int caps[4] = {0, split ? 170 : 0, split ? 340 : 0, RESCUE_LDS_REGS};
+		for (int c = 2; c >= 0; --c) { // the longest first: their tail is what the launch ends on
+			if (caps[c + 1] <= caps[c]) continue;
+			const int per_cu = c == 0 ? 5 : c == 1 ? 3 : 2, blocks = n < n_cu * per_cu ? n : n_cu * per_cu;
+			hipLaunchKernelGGL(k_rescue_heavy, dim3(blocks), dim3(64), (size_t)caps[c + 1] * sizeof(Reg), stream, f, list, n, wave, caps[c], caps[c + 1], cur + c);
+		}
 		ARX_HIP_CHECK(hipGetLastError());
 	});
 	wsort_report(stream, nm);
@@ -168,7 +191,7 @@ template <> void HipRT::run_chain_heavy<KChain>(const char *nm, int n_reads, con
 	// f.n_heavy[0]: the list's length (stays on the device), [1] and [2]: the two launches' cursors into it
 	static const int l_div = getenv("ARX_CHAIN_L_DIV") ? atoi(getenv("ARX_CHAIN_L_DIV")) : 1; // the long ones' launch holds 128 KB of LDS per workgroup: on n_cu / l_div CUs
 	on_aux([&]() { hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu / (l_div > 0 ? l_div : 1)), dim3(64), lds_l, stream, f, CHAIN_LDS_SMALL + 1, CHAIN_LDS_OCC, f.n_heavy + 2, wave); }); // the few long ones (beside the rest with ARX_AUX_STREAM=1)
-	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu * 4), dim3(64), lds_s, stream, f, 0, CHAIN_LDS_SMALL, f.n_heavy + 1, wave);
+	hipLaunchKernelGGL(k_chain_heavy, dim3(n_cu * 4), dim3(64), lds_s, stream, f, 0, CHAIN_LDS_SMALL, f.n_heavy + 1, wave); // (a third launch for reads of up to 128 occurrences at half the LDS changed nothing: round 3)
 	ARX_HIP_CHECK(hipGetLastError());
 	aux_join();
 #ifdef ARX_CHAIN_STATS

@@ -57,6 +57,8 @@ struct IndexView {
 	uint64_t primary, seq_len, L2[5];
 	int64_t l_pac;
 	int32_t n_seqs, sa_intv;
+	// bi-interval of every ktab_k-mer (dev_fm.h: ktab_*), built when the index is opened; null / 0: none
+	const uint64_t *ktab; int32_t ktab_k, pad_;
 };
 
 struct Biv { uint64_t k, l, s, info; };  // bwtintv_t (bwt.h:59): k = x[0], l = x[1], s = x[2], info = beg<<32|end

@@ -175,6 +175,23 @@ ARX_DEVI Biv set_intv(const IndexView &ix, int c) // bwt_set_intv (bwt.h:78)
 	return ik;
 }
 
+// ---- k-mer table.  The bi-interval a forward extension reaches after its first K bases is a pure function of those K bases: a table
+// of 4^K entries, filled once per arx_open by the very extension it replaces (level d + 1 from level d, api_impl.h), turns K - 1
+// DEPENDENT extensions (two scattered Occ blocks each) into one independent 16-byte load.  Entry of the K-mer q[0..K) with code
+// sum q[i] << 2i: k (40 bits) | l (40 bits) | s (40 bits) in two 64-bit words -- 2^40 symbols is what the Occ blocks hold as well.
+ARX_DEVI void ktab_pack(const Biv &b, uint64_t *w) { w[0] = (b.k & 0xffffffffffull) | (b.l & 0xffffffull) << 40; w[1] = ((b.l >> 24) & 0xffffull) | (b.s & 0xffffffffffull) << 16; }
+ARX_DEVI Biv ktab_unpack(uint64_t w0, uint64_t w1)
+{
+	Biv b; b.k = w0 & 0xffffffffffull; b.l = (w0 >> 40) | (w1 & 0xffffull) << 24; b.s = w1 >> 16; b.info = 0;
+	return b;
+}
+ARX_DEVI Biv ktab_load(const IndexView &ix, uint64_t code)
+{
+	struct alignas(16) W2 { uint64_t a, b; };
+	const W2 w = *(const W2 *)(ix.ktab + 2 * code);
+	return ktab_unpack(w.a, w.b);
+}
+
 // one LF step of bwt_invPsi (bwt.c:53-59)
 ARX_DEVI uint64_t lf_step(const IndexView &ix, uint64_t k)
 {
@@ -404,10 +421,16 @@ ARX_DEV int seed_gather_pass2(const SeedPools &P, int first2, Biv *out, int n, i
 // results of the first two passes, so it is its own lane program (forward extensions only, next to no bookkeeping) and
 // runs as its own kernel; seed_merge() joins the two interval lists.
 constexpr int CAP_STRAT = 16; // a hit consumes at least min_seed_len + 1 bases: <= MAX_READ_LEN / 20 hits per read
+// With a k-mer table (ix.ktab, K = ix.ktab_k <= min_seed_len): nothing a start does before its match is min_seed_len + 1 long can be
+// observed -- bwt_seed_strategy1 only looks at an interval once i - x >= min_len (bwt.c:370) -- so a start whose next min_seed_len bases
+// are all A/C/G/T and inside the read jumps to the interval of its first K bases (advance() asks for it with *rc = -1, req->k = the
+// K-mer's code; consume_tab() takes it); a start that meets an N or the end of the read first cannot yield anything and is passed over
+// exactly as the base-by-base walk would leave it (restart behind the N; end of the pass).
 template <class Q> struct StratLane {
 	Q q; Biv *out; int len, n, x, i, sx; bool fresh, finished; Biv ik;
 	ARX_DEVI void start(int len_, const Q &q_, Biv *out_) { q = q_; out = out_; len = len_; n = 0; x = 0; i = 0; sx = 0; fresh = true; finished = false; ik = Biv(); }
 	ARX_DEVI bool done() const { return finished; }
+	ARX_DEVI void consume_tab(const IndexView &ix, const Biv &t) { ik = t; i = sx + ix.ktab_k; }
 	ARX_DEVI bool advance(const IndexView &ix, Biv *req, int *rc)
 	{
 		for (;;) {
@@ -415,6 +438,19 @@ template <class Q> struct StratLane {
 				while (x < len && q.at(x) > 3) ++x;
 				if (x >= len) { finished = true; return false; }
 				ik = set_intv(ix, q.at(x)); sx = x; i = x + 1; fresh = false;
+				if (ix.ktab) {
+					if (sx + OPT_MIN_SEED_LEN >= len) { finished = true; return false; } // the walk would reach the end of the read (or an N, and then the end from behind it) before any match is long enough
+					uint64_t code = (uint64_t)q.at(sx);
+					int bad = -1;
+					for (int p = 1; p <= OPT_MIN_SEED_LEN; ++p) {
+						const int b = q.at(sx + p);
+						if (b > 3) { bad = sx + p; break; }
+						if (p < ix.ktab_k) code |= (uint64_t)b << (2 * p);
+					}
+					if (bad >= 0) { x = bad + 1; fresh = true; continue; }
+					req->k = code; *rc = -1;
+					return true;
+				}
 			}
 			if (i >= len) { finished = true; return false; } // bwt_seed_strategy1 returns len: the pass ends
 			if (q.at(i) > 3) { x = i + 1; fresh = true; continue; }

@@ -711,7 +711,10 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_strat_dyn(StratArgs
 			need = ln.advance(A.ix, &req, &rc);
 			if (!need) { A.n_strat[r] = ln.n; r = -1; }
 		}
-		if (need) ln.consume(extend1(A.ix, req, 0, rc));
+		if (need) {
+			if (rc < 0) ln.consume_tab(A.ix, ktab_load(A.ix, req.k)); // a new start: the interval of its first K bases (dev_fm.h: k-mer table)
+			else ln.consume(extend1(A.ix, req, 0, rc));
+		}
 	}
 }
 

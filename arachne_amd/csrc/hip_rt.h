@@ -148,6 +148,8 @@ struct HipRT {
 		return stage_buf;
 	}
 	void h2d_staged(void *d, const void *staged, size_t bytes) { if (bytes) ARX_HIP_CHECK(hipMemcpyAsync(d, staged, bytes, hipMemcpyHostToDevice, stream)); }
+	uint64_t free_bytes() const { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? (uint64_t)f : 0; }
+	void d2d(void *d, const void *s, size_t bytes) { if (bytes) ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
 	void memset0(void *d, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, 0, bytes, stream)); }
 	void memset_bytes(void *d, int v, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, v, bytes, stream)); }
 	void sync() { ARX_HIP_CHECK(hipStreamSynchronize(stream)); }
@@ -252,6 +254,7 @@ struct HipRT {
 	// chaining of the reads with many seed occurrences, one wavefront per read on a working set in LDS (arx_cold.hip); f.heavy_list / f.n_heavy
 	bool chain_heavy_ok() const { return !(getenv("ARX_CHAIN_HEAVY") && atoi(getenv("ARX_CHAIN_HEAVY")) == 0); }
 	template <class F> void run_chain_heavy(const char *nm, int n_reads, const F &f);
+	bool rescue_heavy_attr_set = false;
 	bool chain_heavy_attr_set = false; // the 128 KB dynamic-LDS opt-in of k_chain_heavy was made on this runtime's device
 	bool dedup_heavy_ok() const { return !(getenv("ARX_DEDUP_HEAVY") && atoi(getenv("ARX_DEDUP_HEAVY")) == 0); }
 	template <class F> void run_dedup_heavy(const char *nm, int n_reads, const F &f); // likewise the region lists of such reads (f.eh_words ints of scratch per workgroup)

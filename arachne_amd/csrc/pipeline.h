@@ -127,7 +127,7 @@ struct KSeedStrat { // pass 3 for one read
 			ln.start(len, QBytes{bases + base_off[r]}, strat + (size_t)r * CAP_STRAT);
 			Biv req = Biv();
 			int rc = 0;
-			while (ln.advance(ix, &req, &rc)) ln.consume(extend1(ix, req, 0, rc));
+			while (ln.advance(ix, &req, &rc)) { if (rc < 0) ln.consume_tab(ix, ktab_load(ix, req.k)); else ln.consume(extend1(ix, req, 0, rc)); }
 			n = ln.n;
 		}
 		n_strat[r] = n;
@@ -490,6 +490,29 @@ public:
 		rt.h2d_staged(b.bases, st, (size_t)tot);
 		rt.h2d_staged(b.base_off, st_off, sizeof(int32_t) * ((size_t)n_reads + 1));
 		rt.h2d_staged(b.lens, st_len, sizeof(int32_t) * (size_t)n_reads);
+	}
+	// The same from arrays that are in device memory already (a batch received from another GPU over RCCL: arachne_amd/shard.py): device-to-device
+	// copies on the batch's stream, the base offsets by a scan on the device; the read lengths come back to the host once (arx_batch_rfa's
+	// host-libm guard needs them).  n_bases / max_len: what the sender's header says; checked against the scan.  The caller's buffers must be
+	// complete when this is called (its own stream synchronised) and may be reused when it returns.
+	bool upload_from_device(DeviceBatch &b, const uint8_t *d_bases, const int32_t *d_lens, int n_reads, int64_t n_bases, int max_len, std::vector<int32_t> &lens_host)
+	{
+		if (n_bases + 16 > b.cap_bases) { rt.pfree(b.bases); b.cap_bases = n_bases + n_bases / 8 + 64; b.bases = rt.template palloc<uint8_t>((size_t)b.cap_bases); }
+		if (n_reads + 1 > b.cap_reads) {
+			rt.pfree(b.base_off); rt.pfree(b.lens);
+			b.cap_reads = n_reads + n_reads / 8 + 8;
+			b.base_off = rt.template palloc<int32_t>((size_t)b.cap_reads); b.lens = rt.template palloc<int32_t>((size_t)b.cap_reads);
+		}
+		b.n_reads = n_reads; b.n_bases = n_bases; b.max_len = max_len;
+		rt.d2d(b.bases, d_bases, (size_t)n_bases);
+		rt.d2d(b.lens, d_lens, sizeof(int32_t) * (size_t)n_reads);
+		const int64_t tot = rt.exclusive_scan(b.lens, b.base_off, n_reads);
+		lens_host.resize((size_t)n_reads);
+		rt.d2h(lens_host.data(), b.lens, sizeof(int32_t) * (size_t)n_reads);
+		int mx = 0;
+		for (int i = 0; i < n_reads; ++i) { if (lens_host[i] < 0 || lens_host[i] > MAX_READ_LEN) return false; if (lens_host[i] > mx) mx = lens_host[i]; }
+		b.max_len = mx;
+		return tot == n_bases;
 	}
 	DeviceBatch upload(const uint8_t *bases, const int32_t *lens, int n_reads)
 	{

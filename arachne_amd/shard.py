@@ -118,6 +118,122 @@ def gather_results(xch, rank, world, mine):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Device-resident form of the same dataflow (round 3): a packed batch travels as ONE byte tensor in the memory of the backend's device
+# (GPU memory for nccl = RCCL over xGMI; host memory for gloo), the receiving rank hands the library pointers into it
+# (arx_batch_reset_device: device-to-device copies, no host hop) and sends its result slabs from where the library left them
+# (arx_batch_device_view) -- the host sees a rank's reads and results only at the ingest rank.  All transfers of a phase are posted together
+# (torch.distributed.batch_isend_irecv) and the ingest rank runs its own batch while its sends are in flight.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _field_offsets(hdr, fields):
+    offs, o = [], 0
+    for (k, dt), n in zip(fields, [int(x) for x in hdr]):
+        nb = n * np.dtype(dt).itemsize
+        offs.append((o, nb))
+        o += nb + ((-nb) % 8)
+    return offs, o
+
+
+class _DevArray:
+    """a device pointer as something torch.as_tensor understands (the CUDA array interface; torch on ROCm speaks it for HIP memory)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = dict(shape=(int(nbytes),), typestr="|u1", data=(int(ptr), False), version=2, strides=None)
+
+
+def _wrap_bytes(xch, ptr, nbytes):
+    """nbytes at `ptr` (memory of the exchange's device) as a uint8 tensor, no copy"""
+    torch = xch.torch
+    if nbytes == 0 or not ptr:
+        return torch.zeros(0, dtype=torch.uint8, device=xch.device)
+    if xch.device == "cpu":
+        import ctypes
+        return torch.from_numpy(np.frombuffer((ctypes.c_uint8 * int(nbytes)).from_address(int(ptr)), dtype=np.uint8))
+    return torch.as_tensor(_DevArray(ptr, nbytes), device=xch.device)
+
+
+def step_device(xch, rank, world, ref, packed_per_rank, handle=None):
+    """One scatter -> run -> gather step with device-resident payloads.  packed_per_rank: at rank 0 the packed batches (pack()) of all ranks,
+    elsewhere None.  -> (per-rank result slabs as host arrays at rank 0, None elsewhere; this rank's batch handle for reuse)."""
+    torch, dist = xch.torch, xch.dist
+    P2P = dist.P2POp
+    nf_in, nf_out = len(_FIELDS_IN), len(_FIELDS_OUT)
+
+    def wait(works):
+        for w in works:
+            w.wait()
+
+    # ---- scatter: headers, then payloads; rank 0 posts every peer's transfer at once
+    pending, keep = [], []
+    if rank == 0:
+        hdrs, pays = [], []
+        for r in range(1, world):
+            h, p = _to_bytes(packed_per_rank[r], _FIELDS_IN)
+            hdrs.append(xch._t(np.concatenate([[len(p)], h]).astype(np.int64)))
+            pays.append(xch._t(p))                      # the one host -> device copy of this rank's reads, at the ingest rank
+        # two groups, as the receivers post them: every peer's header, then every peer's payload (a group is matched as a whole)
+        pending = dist.batch_isend_irecv([P2P(dist.isend, hdrs[r - 1], r) for r in range(1, world)]) if world > 1 else []
+        ops = [P2P(dist.isend, pays[r - 1], r) for r in range(1, world) if len(pays[r - 1])]
+        pending += dist.batch_isend_irecv(ops) if ops else []
+        keep = [hdrs, pays]
+        mine = packed_per_rank[0]
+        hdr_in = np.array([len(mine[k]) for k, _ in _FIELDS_IN], dtype=np.int64)
+        pay_in = xch._t(_to_bytes(mine, _FIELDS_IN)[1])
+    else:
+        h = torch.zeros(nf_in + 1, dtype=torch.int64, device=xch.device)
+        wait(dist.batch_isend_irecv([P2P(dist.irecv, h, 0)]))
+        hh = h.cpu().numpy()
+        pay_in = torch.zeros(int(hh[0]), dtype=torch.uint8, device=xch.device)
+        if int(hh[0]):
+            wait(dist.batch_isend_irecv([P2P(dist.irecv, pay_in, 0)]))
+        hdr_in = hh[1:]
+    # ---- run: pointers into the payload go straight to the library
+    offs, _tot = _field_offsets(hdr_in, _FIELDS_IN)
+    n_reads = int(hdr_in[1])
+    slabs = None
+    if n_reads > 0:
+        if xch.device != "cpu":
+            torch.cuda.current_stream().synchronize()   # the payload is complete before another stream reads it
+        base = pay_in.data_ptr()
+        bco = pay_in[offs[2][0]:offs[2][0] + offs[2][1]].cpu().numpy().view(np.int64)       # barcode offsets and flags: host arguments of arx_batch_rfa, a few KB
+        flags = pay_in[offs[3][0]:offs[3][0] + offs[3][1]].cpu().numpy()
+        if handle is None:
+            handle = ref.batch(np.zeros((2, 0), np.uint8), np.zeros(2, np.int32))
+        handle.reset_device(n_reads, int(hdr_in[0]), base + offs[0][0], base + offs[1][0])
+        handle.run()
+        handle.rfa(bco, flags, fetch=False)
+        view = handle.device_view()
+        slabs = {k: _wrap_bytes(xch, view[k][0], view[k][1] * view[k][2].itemsize) for k, _ in _FIELDS_OUT}
+        counts = np.array([view[k][1] for k, _ in _FIELDS_OUT], dtype=np.int64)
+    else:
+        counts = np.array([1, 0, 0, 0, 1, 0], dtype=np.int64)
+        slabs = {k: torch.zeros(4 if k in ("reg_off", "cand_off") else 0, dtype=torch.uint8, device=xch.device) for k, _ in _FIELDS_OUT}
+    wait(pending)
+    del keep
+    # ---- gather: every rank's counts, then its six slabs, all posted together at rank 0
+    if rank != 0:
+        wait(dist.batch_isend_irecv([P2P(dist.isend, xch._t(counts), 0)]))
+        ops = [P2P(dist.isend, slabs[k], 0) for k, _ in _FIELDS_OUT if len(slabs[k])]
+        if ops:
+            wait(dist.batch_isend_irecv(ops))
+        return None, handle
+    cnt = [torch.zeros(nf_out, dtype=torch.int64, device=xch.device) for _ in range(1, world)]
+    if world > 1:
+        wait(dist.batch_isend_irecv([P2P(dist.irecv, cnt[r - 1], r) for r in range(1, world)]))
+    got, ops = [], []
+    for r in range(1, world):
+        c = cnt[r - 1].cpu().numpy()
+        t = {k: torch.zeros(int(n) * np.dtype(dt).itemsize, dtype=torch.uint8, device=xch.device) for (k, dt), n in zip(_FIELDS_OUT, c)}
+        ops += [P2P(dist.irecv, t[k], r) for k, _ in _FIELDS_OUT if len(t[k])]
+        got.append(t)
+    if ops:
+        wait(dist.batch_isend_irecv(ops))
+    out = []
+    for t in [slabs] + got:                             # one device -> host copy per slab, at the ingest rank, where the host consumer is
+        out.append({k: t[k].cpu().numpy().view(dt).copy() for k, dt in _FIELDS_OUT})
+    return out, handle
+
+
 def run_batch(ref, packed, handle=None):
     """One packed batch through the whole path on this rank's GPU -> result slabs (host arrays); handle: a Batch to reuse."""
     if len(packed["lens"]) == 0:

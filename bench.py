@@ -459,22 +459,13 @@ def main():
             packed = [shard.pack(seqs_all, lens_all, po_all, flags_all, a) for a in assign]
             del sets_all, seqs_all
 
+        state = dict(h=None)
+
         def scatter_step():
-            mine_p = shard.scatter_batches(xch, rank, world, packed)
-            bpo = mine_p["bc_pair_off"]; boff = np.concatenate([[0], np.cumsum(mine_p["lens"], dtype=np.int64)])
-            cuts = [int(np.searchsorted(bpo, bpo[-1] * k / nb)) for k in range(nb + 1)]   # nb device batches of whole barcodes, about equal in pairs
-            cuts[0], cuts[-1] = 0, len(bpo) - 1
-            for i, b in enumerate(batches):
-                c0, c1 = cuts[i], max(cuts[i + 1], cuts[i])
-                p0, p1 = int(bpo[c0]), int(bpo[c1])
-                b.host = (mine_p["bases"][boff[2 * p0]:boff[2 * p1]], mine_p["lens"][2 * p0:2 * p1])
-                b.bc_pair_off = (bpo[c0:c1 + 1] - bpo[c0]).astype(np.int64); b.do_rfa = mine_p["do_rfa"][c0:c1]
-            run_steps(1, boundary=True)
-            for b in batches:
-                c = b.counts()
-                slab = dict(reg_off=b.out["reg_off"][:b.n_reads + 1], regs=b.out["regs"][:c["n_regs"]], alns=b.out["alns"][:c["n_regs"]], cigars=b.out["cigars"][:c["n_cigar"]],
-                            cand_off=b.out["cand_off"][:b.n_reads + 1], cands=b.out["cands"][:b._n_cands])
-                shard.gather_results(xch, rank, world, slab)
+            # device-resident payloads (arachne_amd/shard.py: step_device): every peer's transfer posted together, the library reads the received
+            # tensor and hands out its result slabs where they lie; one device batch per rank and step
+            gathered, state["h"] = shard.step_device(xch, rank, world, ref, packed, state["h"])
+            return gathered
 
         scatter_step()
         barrier()
@@ -486,8 +477,10 @@ def main():
         if rank == 0:
             loads = [int(np.diff(po_all)[a].sum()) for a in assign]
             scatter_info = dict(value=world * rs.n_pairs * args.scatter_steps / ts, unit="paired reads/s", steps=args.scatter_steps, ms_per_step=1000.0 * ts / args.scatter_steps,
-                                pairs_per_rank=loads, note="rank 0 owns all barcodes, LPT assignment of whole barcodes by pair count, packed batches scattered and result slabs "
-                                "gathered with torch.distributed send/recv (%s) inside every step; bounded by the ingest rank's packing and host copies, not by the GPUs" % args.backend)
+                                pairs_per_rank=loads, note="rank 0 owns all barcodes, LPT assignment of whole barcodes by pair count; packed batches travel as device tensors "
+                                "(torch.distributed batch_isend_irecv over %s, all peers posted together), the library reads them in place (arx_batch_reset_device) and the result "
+                                "slabs are sent from where it left them (arx_batch_device_view); the ingest rank runs its own batch while its sends are in flight and copies every "
+                                "rank's slabs to the host once" % args.backend)
     mine = dict(rank=rank, pairs=int(rs.n_pairs), regs=int(sum(c["n_regs"] for c in counts)), read_seed=SEED0 + 1000 * (rank + 1))
     per_rank = [mine]
     if dist is not None:

@@ -77,6 +77,20 @@ int arx_batch_reset(arx_ctx *ctx, arx_batch *b, int32_t n_reads, const uint8_t *
 int arx_batch_run(arx_ctx *ctx, arx_batch *b, int32_t last_stage);
 /* counts[8] = n_reads, n_regs, n_cigar_words, seed occurrences, extension rounds, extension DPs, rescue rounds, rescue SWs */
 int arx_batch_counts(arx_ctx *ctx, arx_batch *b, int64_t *counts);
+/* ---- device-resident boundary (multi-GPU dataflow): a batch whose reads are in the memory of this context's GPU already
+ * -- received from the ingest GPU over RCCL -- and result slabs handed out where they lie, for a send without a host copy.
+ * arx_batch_reset_device: arx_batch_reset from device pointers (d_bases: n_bases codes 0..4; d_lens: n_reads lengths); the caller's
+ * buffers must be complete when it is called and may be reused when it returns.  arx_batch_device_view: the dense result arrays of
+ * arx_batch_fetch / arx_batch_rfa_fetch in device memory (cand_off / cands NULL before arx_batch_rfa); valid until the batch is run, reset
+ * or freed; the call waits for the batch's stream.  (In the host test double "device" memory is host memory.) */
+typedef struct {
+	int64_t n_reads, n_regs, n_cigar, n_cands;
+	const int32_t *reg_off; const arx_reg *regs; const arx_aln *alns; const uint32_t *cigars;
+	const int32_t *cand_off; const struct arx_cand_ *cands;
+} arx_device_view;
+int arx_batch_reset_device(arx_ctx *ctx, arx_batch *b, int32_t n_reads, int64_t n_bases, const uint8_t *d_bases, const int32_t *d_lens);
+int arx_batch_device_view(arx_ctx *ctx, arx_batch *b, arx_device_view *view);
+
 /* reg_off[n_reads+1], regs[n_regs], alns[n_regs], cigars[n_cigar_words]: caller-allocated from arx_batch_counts */
 int arx_batch_fetch(arx_ctx *ctx, arx_batch *b, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars);
 void arx_batch_free(arx_ctx *ctx, arx_batch *b);
@@ -85,7 +99,7 @@ void arx_batch_free(arx_ctx *ctx, arx_batch *b);
  * tagBestAlignments :1397, inferMolecules :1300 ... optimizer.Optimize (src/optimizer/optimizer.go:15) and estimateMapQualities :797.
  * Needs arx_batch_run(..., ARX_STAGE_ALN) first.  One candidate per region, or one placeholder (reg = -1, pos = -1) for a read
  * without regions; `active` marks the placement chosen for the read, `mapq` is set on active candidates. */
-typedef struct {
+typedef struct arx_cand_ {
 	int64_t pos, aend;              /* Alignment.pos / .aend (0-based, reverse-strand candidates swapped +1, aligner.go:1577-1582) */
 	double sum_move;                /* 1 + sum of 10^fastScore over sink molecules (method 2) */
 	int32_t reg, read, rid, reversed, score, mismatches, indels, soft_clipped, soft_clipped_length;

@@ -16,6 +16,8 @@ def main():
     from arachne_amd import api, shard, synth
     import workloads
     out_dir, lib = sys.argv[1], sys.argv[2]
+    mode = sys.argv[3] if len(sys.argv) > 3 else "host"                     # "device": payloads as tensors the library reads / writes in place
+    sizes_arg = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else None
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     prefix = os.path.join(out_dir, "g.fa")
@@ -26,8 +28,8 @@ def main():
         g.write_alt(prefix + ".alt")
         api.index_build(prefix, prefix)
         # barcodes of very different sizes, so that the LPT assignment is not the trivial split
-        sizes = [90, 7, 40, 3, 25, 61, 12]
-        parts = [synth.make_reads(500 + i, g, 1, n, molecule_len=15000, molecules_per_barcode=3, sub_rate=0.01) for i, n in enumerate(sizes)]
+        sizes = sizes_arg or [90, 7, 40, 3, 25, 61, 12]
+        parts = [synth.make_reads(500 + i, g, 1, n, molecule_len=15000, molecules_per_barcode=3 if n < 1000 else 40, sub_rate=0.01) for i, n in enumerate(sizes)]
         seqs = np.concatenate([p.seqs for p in parts]); lens = np.concatenate([p.lens for p in parts])
         pair_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         do_rfa = np.array([api.worth_running_rfa("A01C01B01D01-1", n) for n in sizes], dtype=np.uint8)
@@ -38,9 +40,14 @@ def main():
     dist.barrier()                                       # the index files exist
     ref = api.Reference(prefix, lib_path=lib)
     xch = shard.Exchange(dist, "cpu")
-    mine = shard.scatter_batches(xch, rank, world, packed)
-    res, _h = shard.run_batch(ref, mine)
-    gathered = shard.gather_results(xch, rank, world, res)
+    if mode == "device":
+        gathered, _h = shard.step_device(xch, rank, world, ref, packed)
+        if world > 1:                                                       # a second step through the same handles (reset_device on a used batch)
+            gathered, _h = shard.step_device(xch, rank, world, ref, packed, _h)
+    else:
+        mine = shard.scatter_batches(xch, rank, world, packed)
+        res, _h = shard.run_batch(ref, mine)
+        gathered = shard.gather_results(xch, rank, world, res)
     if rank == 0:
         merged = shard.merge_in_read_set_order(gathered, assign, pair_off)
         whole, _h2 = shard.run_batch(ref, shard.pack(seqs, lens, pair_off, do_rfa, np.arange(len(sizes))))   # N = 1: one batch over everything
