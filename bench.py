@@ -539,7 +539,9 @@ def main():
                 # memory-side bytes of the same kernels from the committed rocprofv3 --pmc FETCH_SIZE pass of this command (counters
                 # cannot be read from inside the process); null when no such pass is committed
                 traffic, traffic_src = None, None
-                rel = os.path.join("profiles", "r02", "seed_traffic_%s.json" % args.workload)
+                rel = os.path.join("profiles", "r03", "seed_traffic_%s.json" % args.workload)
+                if not os.path.exists(os.path.join(ROOT, rel)):
+                    rel = os.path.join("profiles", "r02", "seed_traffic_%s.json" % args.workload)
                 tf = os.path.join(ROOT, rel)
                 if os.path.exists(tf):
                     tj = json.load(open(tf))
@@ -725,7 +727,7 @@ def main():
                     for b in bs:
                         b.free()
                 sets, batches = [], []
-                st = e2e.run(ref, files, os.path.join(ed, "out"), pairs_per_batch=max(20000, rs.n_pairs // (3 * k)), bam_threads=8, rec_threads=8,
+                st = e2e.run(ref, files, os.path.join(ed, "out"), pairs_per_batch=max(20000, rs.n_pairs // (2 * k)), bam_threads=8, rec_threads=8,
                              lib_path=args.lib or api.LIB_PATH)
                 out["end_to_end"] = dict(value=st["pairs_per_s"], unit="paired reads/s", pairs=st["pairs"], seconds=round(st["seconds"], 3), workers=k,
                                          fastq_bytes=sum(os.path.getsize(f) for pr in files for f in pr), bam_bytes=st.get("bam_bytes"), fastq_write_s=round(t_w, 2),
