@@ -136,16 +136,29 @@ __device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint8_t *zl, uint32_t 
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			if (l == 0) {
-				while (i >= lo && k >= 0) {
-					which = zl[(i - lo) * stride + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
-					if (op == run_op) ++run_len;
-					else { if (run_op >= 0) { if (n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = op; run_len = 1; }
-					if (which == 0) { --i; --k; } else if (which == 1) --i; else --k;
+			// every lane of the group walks the same path (the reads are broadcasts); while the walk is on a diagonal the 16 lanes look at the next
+			// 16 cells of it at once and the run of matches up to the first cell that leaves the diagonal is taken in one step -- lane 0 alone,
+			// one cell per step, was the longest serial stretch of this kernel (the DP rows are done by the group, the walk was not)
+			while (i >= lo && k >= 0) {
+				if (which == 0) {
+					const int ii = i - l, kk = k - l;
+					const bool valid = ii >= lo && kk >= 0;
+					const int b = valid ? zl[(ii - lo) * stride + (kk - (ii > w ? ii - w : 0))] : 3;
+					const unsigned m16 = (unsigned)(__ballot(valid && (b & 3) == 0) >> (__lane_id() & 48)) & 0xffffu;
+					const int J = __builtin_ctz(~m16); // cells ahead that stay on the diagonal (0..16)
+					if (J > 0) {
+						if (run_op == 0) run_len += J;
+						else { if (run_op >= 0) { if (l == 0 && n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = 0; run_len = J; }
+						i -= J; k -= J;
+						continue;
+					}
 				}
+				which = zl[(i - lo) * stride + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+				const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
+				if (op == run_op) ++run_len;
+				else { if (run_op >= 0) { if (l == 0 && n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = op; run_len = 1; }
+				if (which == 0) { --i; --k; } else if (which == 1) --i; else --k;
 			}
-			i = g16_bcast0(i); k = g16_bcast0(k);
 		}
 		if (l == 0) {
 			if (i >= 0) { if (run_op == 2) run_len += i + 1; else { if (run_op >= 0) { if (n < cap) cg[n] = (uint32_t)run_len << 4 | run_op; ++n; } run_op = 2; run_len = i + 1; } }
@@ -158,8 +171,14 @@ __device__ int nw_g16(const NwSeg &sg, int w, uint8_t *z, uint8_t *zl, uint32_t 
 	return last_h;
 }
 
-// bwa_gen_cigar2 for a region already staged in LDS (score, CIGAR, NM); every lane returns the same values
-__device__ void gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint8_t *zl, uint32_t *cg, int cap, int *score, int *n_cigar, int *NM)
+// bwa_gen_cigar2 for a region already staged in LDS (score, CIGAR, NM); every lane returns the same values.
+// LO / HI: the lane tilings (band columns per lane) this instantiation holds.  The kernel is compiled once per band class with only the
+// tilings that class can need -- its own and the one a doubled band takes -- because the registers of the widest tiling are what set
+// the occupancy of the whole kernel (180 VGPRs, two wavefronts per SIMD, with all five in one kernel; the dependent chain of a DP row
+// needs many more to hide).  Returns false when the band needs a wider tiling than HI: the caller hands the region to the launch that
+// holds them all.
+template <int LO, int HI>
+__device__ bool gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint8_t *zl, uint32_t *cg, int cap, int *score, int *n_cigar, int *NM)
 {
 	const int l = __lane_id() & 15;
 	const int l_query = sg.qlen, rlen = sg.tlen;
@@ -179,41 +198,46 @@ __device__ void gen_cigar2_g16(const NwSeg &sg, int w_, uint8_t *z, uint8_t *zl,
 		w = w > min_w ? w : min_w;
 		const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
 		int n = 0;
-		if (n_col <= 16) sc = nw_g16<1>(sg, w, z, zl, cg, cap, &n);
-		else if (n_col <= 32) sc = nw_g16<2>(sg, w, z, zl, cg, cap, &n);
-		else if (n_col <= 64) sc = nw_g16<4>(sg, w, z, zl, cg, cap, &n);
-		else if (n_col <= 128) sc = nw_g16<8>(sg, w, z, zl, cg, cap, &n);
-		else sc = nw_g16<16>(sg, w, z, zl, cg, cap, &n);
+		if (n_col > 16 * HI) return false;
+		if (LO <= 1 && n_col <= 16) sc = nw_g16<1>(sg, w, z, zl, cg, cap, &n);
+		else if (LO <= 2 && HI >= 2 && n_col <= 32) sc = nw_g16<(HI >= 2 ? 2 : HI)>(sg, w, z, zl, cg, cap, &n);
+		else if (LO <= 4 && HI >= 4 && n_col <= 64) sc = nw_g16<(HI >= 4 ? 4 : HI)>(sg, w, z, zl, cg, cap, &n);
+		else if (LO <= 8 && HI >= 8 && n_col <= 128) sc = nw_g16<(HI >= 8 ? 8 : HI)>(sg, w, z, zl, cg, cap, &n);
+		else sc = nw_g16<HI>(sg, w, z, zl, cg, cap, &n);
 		nc = g16_bcast0(n);
 	}
 	int nm = -1;
 	if (nc <= cap) { // NM = mismatches + gap bases; a leading/trailing D is not counted (bwa.c:169-199)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		if (l == 0) {
-			int x = 0, y = 0, n_mm = 0, n_gap = 0;
-			for (int k = 0; k < nc; ++k) {
-				const int op = cg[k] & 0xf, len = cg[k] >> 4;
-				if (op == 0) { for (int i = 0; i < len; ++i) if (sg.q[x + i] != sg.t[y + i]) ++n_mm; x += len; y += len; }
-				else if (op == 2) { if (k > 0 && k < nc - 1) n_gap += len; y += len; }
-				else if (op == 1) { x += len; n_gap += len; }
-			}
-			nm = n_mm + n_gap;
+		// every lane reads the CIGAR; the bases of a match run are compared 16 at a time
+		int x = 0, y = 0, n_mm = 0, n_gap = 0;
+		for (int k = 0; k < nc; ++k) {
+			const int op = cg[k] & 0xf, len = cg[k] >> 4;
+			if (op == 0) { for (int i = l; i < len; i += 16) n_mm += sg.q[x + i] != sg.t[y + i] ? 1 : 0; x += len; y += len; }
+			else if (op == 2) { if (k > 0 && k < nc - 1) n_gap += len; y += len; }
+			else if (op == 1) { x += len; n_gap += len; }
 		}
-		nm = g16_bcast0(nm);
+		n_mm += dpp_rowz<DPP_ROW_ROR + 8>(n_mm); n_mm += dpp_rowz<DPP_ROW_ROR + 4>(n_mm); n_mm += dpp_rowz<DPP_ROW_ROR + 2>(n_mm); n_mm += dpp_rowz<DPP_ROW_ROR + 1>(n_mm);
+		nm = n_mm + n_gap;
 	}
 	*score = sc; *n_cigar = nc; *NM = nm;
+	return true;
 }
 
 struct NwArgs {
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens, *preg_off, *n_regs; int n_reads; const Reg *pregs;
 	Aln *alns; uint32_t *cig; int cig_w; uint8_t *z; const int32_t *z_off; const int32_t *list; uint32_t *err;
 	const int32_t *order; // queue positions in the order they are taken (one band class per launch)
+	int32_t *punt, *n_punt; // queue positions whose retry wants a wider tiling than their class kernel holds; taken by the launch with all tilings
 };
 
-// mem_reg2aln for queued region list[i]; z_off in 64-byte units
-static __global__ void __launch_bounds__(64) k_reg2aln_nw_g16(NwArgs A, int n)
+// mem_reg2aln for queued region list[i]; z_off in 64-byte units.  n_dev != null: the number of queued positions is read from the device
+// (the launch behind the class launches that takes what they could not hold)
+template <int LO, int HI>
+__global__ void __launch_bounds__(64) k_reg2aln_nw_g16(NwArgs A, int n, const int32_t *n_dev)
 {
+	if (n_dev) n = *n_dev;
 	__shared__ uint8_t lds_q[4][NW_Q_CAP];
 	__shared__ uint8_t lds_t[4][NW_T_CAP];
 	__shared__ __attribute__((aligned(16))) uint8_t lds_z[4][NW_ZL_BYTES];
@@ -247,17 +271,18 @@ static __global__ void __launch_bounds__(64) k_reg2aln_nw_g16(NwArgs A, int n)
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		int NM = -1, score = 0, n_cigar = 0, last_sc = -(1 << 30), i = 0;
-		bool overflow = false;
+		bool overflow = false, punted = false;
 		uint8_t *z = A.z + (size_t)A.z_off[it] * 64;
 		do {
 			w2 = w2 < OPT_W << 2 ? w2 : OPT_W << 2;
 			n_cigar = 0; NM = -1;
-			if (ok) gen_cigar2_g16(sg, w2, z, lds_z[grp], cg + 1, cap - 2, &score, &n_cigar, &NM); // room for both clips
+			if (ok && !gen_cigar2_g16<LO, HI>(sg, w2, z, lds_z[grp], cg + 1, cap - 2, &score, &n_cigar, &NM)) { punted = true; break; } // (cg + 1: room for both clips)
 			if (n_cigar > cap - 2) { overflow = true; break; }
 			if (score == last_sc || w2 == OPT_W << 2) break;
 			last_sc = score;
 			w2 <<= 1;
 		} while (++i < 3 && score < ar.truesc - OPT_A);
+		if (punted) { if (l == 0) A.punt[atomicAdd(A.n_punt, 1)] = it; __builtin_amdgcn_wave_barrier(); continue; }
 		if (overflow) { if (l == 0) atomicOr(A.err, ERR_CIGAR_OVERFLOW); continue; }
 		if (l == 0) {
 			a.NM = NM;

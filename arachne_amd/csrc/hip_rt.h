@@ -515,13 +515,30 @@ struct HipRT {
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch_small(nm, n, f); return; }
-		for (int c = 0; c < NW_CLASSES; ++c) { // one launch per band class: the four groups of a wavefront then run the same tiling
+		// one launch per band class: the four groups of a wavefront then run the same tiling, and the class kernel holds only the tilings the
+		// class can need (its own and the doubled band's): 5 / 4 / 3 / 2 / 2 wavefronts per SIMD instead of 2 for all
+		int32_t *punt = alloc<int32_t>((size_t)n + 4), *n_punt = punt + n;
+		memset0(n_punt, 16);
+		for (int c = 0; c < NW_CLASSES; ++c) {
 			const int nc = n_class[c];
 			if (nc <= 0) continue;
 			Scope sc(*this, nm, nc);
 			NwArgs A{f.ix, f.bases, f.base_off, f.lens, f.preg_off, f.n_regs, f.n_reads, f.pregs, f.alns, f.cig, f.cig_w, zbuf, z_off, f.nw_list, f.err,
-			         f.class_list + (size_t)c * f.class_stride};
-			hipLaunchKernelGGL(k_reg2aln_nw_g16, dim3(coop_blocks(nc)), dim3(64), 0, stream, A, nc);
+			         f.class_list + (size_t)c * f.class_stride, punt, n_punt};
+			const dim3 grid(coop_blocks(nc)), blk(64);
+			switch (c) {
+			case 0: hipLaunchKernelGGL((k_reg2aln_nw_g16<1, 2>), grid, blk, 0, stream, A, nc, (const int32_t *)nullptr); break;
+			case 1: hipLaunchKernelGGL((k_reg2aln_nw_g16<2, 4>), grid, blk, 0, stream, A, nc, (const int32_t *)nullptr); break;
+			case 2: hipLaunchKernelGGL((k_reg2aln_nw_g16<4, 8>), grid, blk, 0, stream, A, nc, (const int32_t *)nullptr); break;
+			case 3: hipLaunchKernelGGL((k_reg2aln_nw_g16<8, 16>), grid, blk, 0, stream, A, nc, (const int32_t *)nullptr); break;
+			default: hipLaunchKernelGGL((k_reg2aln_nw_g16<16, 16>), grid, blk, 0, stream, A, nc, (const int32_t *)nullptr); break;
+			}
+			ARX_HIP_CHECK(hipGetLastError());
+		}
+		{ // what the class kernels handed on (a third band, or a doubled band past the class's second tiling): all tilings, length read on the device
+			Scope sc(*this, nm, 0);
+			NwArgs A{f.ix, f.bases, f.base_off, f.lens, f.preg_off, f.n_regs, f.n_reads, f.pregs, f.alns, f.cig, f.cig_w, zbuf, z_off, f.nw_list, f.err, punt, punt, n_punt + 1};
+			hipLaunchKernelGGL((k_reg2aln_nw_g16<1, 16>), dim3(n_cu * 2), dim3(64), 0, stream, A, 0, (const int32_t *)n_punt);
 			ARX_HIP_CHECK(hipGetLastError());
 		}
 	}
