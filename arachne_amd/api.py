@@ -95,6 +95,11 @@ def _load(path):
     lib.arx_recbuf_error.restype = C.c_char_p
     lib.arx_recbuf_error.argtypes = [vp]
     lib.arx_recbuf_free.argtypes = [vp]
+    lib.arx_multi_open.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp), C.c_char_p, i32]
+    lib.arx_multi_run.argtypes = [vp, i32, vp, vp, i32, vp, vp, C.c_double, vp, vp, vp]
+    lib.arx_multi_error.restype = C.c_char_p
+    lib.arx_multi_error.argtypes = [vp]
+    lib.arx_multi_close.argtypes = [vp]
     lib.arx_kernel_times.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     lib.arx_kernel_times_reset.argtypes = [vp, i32]
     lib.arx_selftest_wave_sort.argtypes = [i32, i32, C.c_int64, vp]
@@ -439,6 +444,46 @@ class RecBuf:
             self.free()
         except Exception:
             pass
+
+
+class _MultiResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_regs", C.c_int64), ("n_cigar", C.c_int64), ("n_cands", C.c_int64), ("reg_off", C.c_void_p), ("regs", C.c_void_p),
+                ("alns", C.c_void_p), ("cigars", C.c_void_p), ("cand_off", C.c_void_p), ("cands", C.c_void_p), ("device_of_barcode", C.c_void_p)]
+
+
+class MultiReference:
+    """Several GPUs behind one handle (arx_multi_*): whole barcodes assigned by pair count, one host thread per device, results in the
+    order of the read set -- what a Go caller binds to drive a node."""
+
+    def __init__(self, prefix: str, devices, lib_path: str = LIB_PATH):
+        self.lib = _load(lib_path)
+        self.h = C.c_void_p()
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        msg = C.create_string_buffer(512)
+        if self.lib.arx_multi_open(prefix.encode(), len(dv), dv.ctypes.data, C.byref(self.h), msg, 512) != 0:
+            self.h = None
+            raise ArachneError("arx_multi_open: " + msg.value.decode())
+
+    def run(self, seqs, lens, bc_pair_off, do_rfa, penalty=-4):
+        """-> dict(reg_off, regs, alns, cigars, cand_off, cands, device_of_barcode) as numpy copies"""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        bases = np.ascontiguousarray(seqs, dtype=np.uint8).reshape(-1)
+        bco = np.ascontiguousarray(bc_pair_off, dtype=np.int64)
+        flags = np.ascontiguousarray(do_rfa, dtype=np.uint8)
+        r = _MultiResult()
+        if self.lib.arx_multi_run(self.h, len(lens), bases.ctypes.data, lens.ctypes.data, len(bco) - 1, bco.ctypes.data, flags.ctypes.data, float(penalty), None, None, C.byref(r)) != 0:
+            raise ArachneError("arx_multi_run: " + self.lib.arx_multi_error(self.h).decode())
+
+        def arr(ptr, n, dt):
+            return np.frombuffer(C.string_at(ptr, int(n) * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dtype=dt)
+        return dict(reg_off=arr(r.reg_off, r.n_reads + 1, np.int32), regs=arr(r.regs, r.n_regs, REG_DTYPE), alns=arr(r.alns, r.n_regs, ALN_DTYPE),
+                    cigars=arr(r.cigars, r.n_cigar, np.uint32), cand_off=arr(r.cand_off, r.n_reads + 1, np.int32), cands=arr(r.cands, r.n_cands, CAND_DTYPE),
+                    device_of_barcode=arr(r.device_of_barcode, len(bco) - 1, np.int32))
+
+    def close(self):
+        if self.h:
+            self.lib.arx_multi_close(self.h)
+            self.h = None
 
 
 def worth_running_rfa(barcode: str, n_pairs: int, unique: bool = True) -> bool:

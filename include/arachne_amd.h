@@ -202,6 +202,26 @@ int arx_recbuf_build(arx_recbuf *rb, const arx_super_batch *sb, const int32_t *c
 const char *arx_recbuf_error(arx_recbuf *rb);
 void arx_recbuf_free(arx_recbuf *rb);
 
+/* ---- several GPUs behind one handle (arx_open(prefix, n_devices, ...)): one index replica per device, a super-batch of whole
+ * barcodes cut by pair count (greedy longest-processing-time), every device's share on a host thread of its own, the result slabs
+ * renumbered into the order of the read set -- byte for byte what ONE batch over everything returns.  devices: HIP device indices or NULL
+ * for 0 .. n_devices - 1.  The result arrays are host memory owned by the handle, valid until the next call on it; device_of_barcode says
+ * where each barcode ran.  (csrc/arx_multi.cpp: host code on the single-device entry points above; the reads reach every GPU from host
+ * memory, so nothing travels between GPUs here -- arachne_amd/shard.py is the RCCL form for reads that arrive on one GPU.) */
+typedef struct arx_multi arx_multi;
+typedef struct {
+	int64_t n_reads, n_regs, n_cigar, n_cands;
+	const int32_t *reg_off; const arx_reg *regs; const arx_aln *alns; const uint32_t *cigars;
+	const int32_t *cand_off; const arx_cand *cands;
+	const int32_t *device_of_barcode; /* n_barcodes: index into the handle's devices */
+} arx_multi_result;
+int arx_multi_open(const char *prefix, int32_t n_devices, const int32_t *devices, arx_multi **out, char *msg, int32_t msg_cap);
+int arx_multi_contigs(arx_multi *m, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens, const int32_t **is_alt, int64_t *l_pac);
+int arx_multi_run(arx_multi *m, int32_t n_reads, const uint8_t *bases, const int32_t *lens, int32_t n_barcodes, const int64_t *bc_pair_off, const uint8_t *do_rfa,
+                  double penalty, const int64_t *cen_start, const int64_t *cen_end, arx_multi_result *out);
+const char *arx_multi_error(arx_multi *m);
+void arx_multi_close(arx_multi *m);
+
 /* intermediate results for parity tests (device -> host copies of stage outputs) */
 #define ARX_CAP_INTV 256
 int arx_batch_debug_intv(arx_ctx *ctx, arx_batch *b, int32_t *n_intv, uint64_t *intv4 /* n_reads*ARX_CAP_INTV*4 */);
