@@ -21,17 +21,22 @@ namespace arx {
 #define ARX_HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 // generic grid-stride launchers; slot = global thread index (always < max_slots) selects per-thread scratch
-template <class F> __global__ void __launch_bounds__(64) k_items(F f, int n)
+#ifndef ARX_ITEMS_WPE
+#define ARX_ITEMS_WPE 1 // (experiments) wavefronts per SIMD the thread-per-item kernels are compiled for
+#endif
+template <class F> __global__ void __launch_bounds__(64, ARX_ITEMS_WPE) k_items(F f, int n)
 {
-	const int slot = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
-	for (int i = slot; i < n; i += step) f(i, slot);
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+	const long long step = (long long)gridDim.x * blockDim.x; // i + step must not wrap: launches of more than 2^30 items exist (arx_open: ARX_SA_DENSE=4 at GRCh38 size)
+	for (long long i = slot; i < n; i += step) f((int)i, slot);
 }
 // DP kernels: each thread owns words [threadIdx.x + j*blockDim.x] of the block's LDS, i.e. a [column][lane] layout
 template <class F> __global__ void __launch_bounds__(64) k_rows(F f, int n)
 {
 	extern __shared__ uint32_t lds_rows[];
-	const int slot = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
-	for (int i = slot; i < n; i += step) f(i, slot, lds_rows + threadIdx.x, (int)blockDim.x);
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+	const long long step = (long long)gridDim.x * blockDim.x;
+	for (long long i = slot; i < n; i += step) f((int)i, slot, lds_rows + threadIdx.x, (int)blockDim.x);
 }
 
 struct CastI64 { __host__ __device__ int64_t operator()(const int32_t &x) const { return (int64_t)x; } };

@@ -15,26 +15,48 @@ from __future__ import annotations
 import threading
 import time
 
+import os
+
 import numpy as np
 
 from . import api
 
+_TRACE = bool(os.environ.get("ARX_E2E_TRACE"))
+
 
 def run(ref: api.Reference, fastq_pairs, out_prefix: str, pairs_per_batch: int = 250_000, bam_threads: int = 8, rec_threads: int = 8, level: int = 1,
-        penalty: float = -4, lib_path: str = api.LIB_PATH):
+        penalty: float = -4, lib_path: str = api.LIB_PATH, warm_passes: int = 0):
     """fastq_pairs: [(r1, r2), ...] barcode-sorted files (plain or gzip), one worker each.  -> stats dict (pairs, seconds, pairs/s, per-stage
-    seconds summed over workers)."""
+    seconds summed over workers).  warm_passes: untimed passes over the same files first, through the same batch handles -- a handle's first
+    batch pays for its work memory (hipMalloc of several GiB: seconds once a 69 GB k-mer table sits beside it), which a run over a whole
+    read set pays once; the stats are those of the last pass."""
     names, offs, clens, alt, l_pac = ref.contigs()
     stats = dict(pairs=0, records=0, batches=0, feeder_s=0.0, device_s=0.0, fetch_s=0.0, records_s=0.0, bam_s=0.0)
     lock = threading.Lock()
     errors = []
 
+    gate = threading.Barrier(len(fastq_pairs) + 1)
+    t_pass = [0.0] * (warm_passes + 2)
+
     def worker(k, r1, r2):
         try:
+            batch, buf = None, {}
+            rb = api.RecBuf(lib_path=lib_path)
+            for ps in range(warm_passes + 1):
+                gate.wait()
+                batch, buf = one_pass(k, r1, r2, batch, buf, rb, ps == warm_passes)
+                gate.wait()
+            if batch is not None:
+                batch.free()
+            rb.free()
+        except BaseException as e:  # noqa: BLE001 -- reported by the caller's thread
+            errors.append(e)
+            gate.abort()
+
+    def one_pass(k, r1, r2, batch, buf, rb, counted):
+        if True:
             fd = api.Feeder(r1, r2, lib_path=lib_path)
             bam = api.BamWriter(f"{out_prefix}.{k}.bam", names, clens, extra_header="@PG\tID:arachne_amd\n", threads=bam_threads, level=level, lib_path=lib_path)
-            rb = api.RecBuf(lib_path=lib_path)
-            batch, buf = None, {}
             loc = dict(pairs=0, records=0, batches=0, feeder_s=0.0, device_s=0.0, fetch_s=0.0, records_s=0.0, bam_s=0.0)
             while True:
                 t0 = time.time()
@@ -47,6 +69,8 @@ def run(ref: api.Reference, fastq_pairs, out_prefix: str, pairs_per_batch: int =
                 batch.run(api.STAGE_ALN)
                 batch.rfa(v["set_pair_off"], v["do_rfa"], penalty=penalty, fetch=False)
                 t2 = time.time()
+                if _TRACE:
+                    print(f"[e2e] worker {k} batch {loc['batches']}: {int(v['n_pairs'])} pairs, feeder {t1 - t0:.3f}s device {t2 - t1:.3f}s", flush=True)
                 batch.fetch_into(buf)
                 post = batch.post_into(buf)
                 t3 = time.time()
@@ -59,26 +83,33 @@ def run(ref: api.Reference, fastq_pairs, out_prefix: str, pairs_per_batch: int =
             t5 = time.time()
             st = bam.close()
             loc["bam_s"] += time.time() - t5
-            if batch is not None:
-                batch.free()
-            rb.free(); fd.close()
-            with lock:
-                for key, val in loc.items():
-                    stats[key] += val
-                stats.setdefault("bam_bytes", 0)
-                stats["bam_bytes"] += st["bytes_out"]
-        except BaseException as e:  # noqa: BLE001 -- reported by the caller's thread
-            errors.append(e)
+            fd.close()
+            if counted:
+                with lock:
+                    for key, val in loc.items():
+                        stats[key] += val
+                    stats.setdefault("bam_bytes", 0)
+                    stats["bam_bytes"] += st["bytes_out"]
+            return batch, buf
 
-    t = time.time()
     th = [threading.Thread(target=worker, args=(k, r1, r2)) for k, (r1, r2) in enumerate(fastq_pairs)]
     for x in th:
         x.start()
+    t = time.time()
+    try:
+        for ps in range(warm_passes + 1):
+            gate.wait()                 # the pass starts
+            t = time.time()
+            gate.wait()                 # ... and is over when every worker has closed its BAM
+            t_pass[ps] = time.time() - t
+    except threading.BrokenBarrierError:
+        pass
     for x in th:
         x.join()
     if errors:
         raise errors[0]
-    stats["seconds"] = time.time() - t
+    stats["seconds"] = t_pass[warm_passes]
+    stats["warm_passes"] = warm_passes
     stats["pairs_per_s"] = stats["pairs"] / stats["seconds"] if stats["seconds"] > 0 else 0.0
     stats["workers"] = len(fastq_pairs)
     return stats

@@ -64,7 +64,7 @@ WORKLOADS = {
     # overlapping the copy; stLFR-like barcodes hold few pairs
     "alt_repeat": dict(lens=GRCH38_LENS, barcodes=33000, ppb=30, molecules=2, seed=20250905 + 4,
                        families=[(10000, 300, 0.12, 0.1), (1000, 6000, 0.05, 0.15), (200, 50000, 0.01, 0.04)] + SEGDUP_FAMILIES,
-                       alt_spec=(220, 100_000, 900_000, 0.01), decoy_spec=(400, 15_000), reads=dict(repeat_bias=0.5, barcode_style="stlfr"),
+                       alt_spec=(220, 100_000, 900_000, 0.01), decoy_spec=(400, 15_000), reads=dict(repeat_bias=0.5, barcode_style="stlfr"), chunk_pairs=350_000, depth=1,
                        label="BASELINE.json configs[3]: GRCh38-size genome + ALT/decoy contigs (%d bp synthetic, 220 .alt-flagged ALT contigs, 400 decoys), "
                              "repeat-enriched stLFR-like set (half of the molecules from planted repeat families / segmental duplications), %d barcodes x %d pairs 2x150bp per step per GPU"),
     # configs[4]: configs[1] with 30 % of the pairs VX:i:0 in dash-less barcodes of 1-4 pairs (worthRunningRFA false, aligner.go:469-477,1018-1030)
@@ -222,8 +222,9 @@ def algorithmic_bytes(prefix, rs, n_sample):
     per_read_strat = 64.0 * (c["ext3_same_block"] + 2 * c["ext3_two_block"]) / reads + L / 4
     per_read_locate = (64.0 * c["sa_lf_steps"] + 8.0 * c["sa_lookups"]) / reads       # the reference's walk: to a sample every 32nd row
     per_read_locate8 = (64.0 * c["sa_lf_steps8"] + 8.0 * c["sa_lookups"]) / reads     # the same lookups walked to a sample every 8th row
+    per_read_locate4 = (64.0 * c.get("sa_lf_steps4", c["sa_lf_steps8"] * 3.0 / 7.0) + 8.0 * c["sa_lookups"]) / reads   # ... every 4th row (the product's default since round 3)
     o.close()
-    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, locate8=per_read_locate8,
+    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, locate8=per_read_locate8, locate4=per_read_locate4,
                 counters={k: v / reads for k, v in c.items() if k != "n_reads"})
 
 
@@ -241,7 +242,8 @@ def main():
     ap.add_argument("--barcodes", type=int, default=0, help="override the workload's barcodes per step")
     ap.add_argument("--pairs-per-barcode", type=int, default=0, help="override the workload's pairs per barcode")
     ap.add_argument("--genome-len", type=int, default=0, help="(experiments) one big contig of this length plus two small ones instead of the workload's genome")
-    ap.add_argument("--chunk-pairs", type=int, default=350_000, help="pairs per device batch inside one step")
+    ap.add_argument("--chunk-pairs", type=int, default=0, help="pairs per device batch inside one step (0: the workload's shape -- one batch per step and two steps in "
+                    "flight on the TELLseq-like sets, three 350,000-pair batches per step on the repeat-rich one whose work memory per pair is several times larger)")
     ap.add_argument("--streams", type=int, default=3, help="device batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,7 +257,7 @@ def main():
                     "inside the timed steps; reported under `scatter_gather` (an ingest rank cannot feed 8 GPUs at kernel rate: see DESIGN.md s6)")
     ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false", help="skip the FASTQ -> BAM pass (reported under `end_to_end`, never as `value`)")
     ap.add_argument("--e2e-workers", type=int, default=6, help="file pairs / worker threads of the end-to-end pass")
-    ap.add_argument("--depth", type=int, default=1, help="batch handles per chunk of the read set (steps in flight)")
+    ap.add_argument("--depth", type=int, default=0, help="batch handles per chunk of the read set (steps in flight); 0: the workload's shape")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="(diagnostics) all batches start together instead of one seeding stage after the other (about 5 %% more throughput, "
                          "but three seeding stages then compete for HBM latency at once and the roofline kernel's time doubles)")
@@ -291,6 +293,14 @@ def main():
     if args.genome_len:
         wl["lens"] = [args.genome_len - 2_000_000, 1_500_000, 500_000] if args.genome_len > 8_000_000 else [args.genome_len]
     n_barcodes, ppb = args.barcodes or wl["barcodes"], args.pairs_per_barcode or wl["ppb"]
+    # Batch shape (round 3, measured on the default command: 350 k x 3 batches per step 8.73 M pairs/s, 520 k x 2 with two steps in flight 8.36 M,
+    # ONE 1,001 k batch per step with two steps in flight 8.95-9.13 M -- the one-wavefront tails of a batch (rescue replay, chaining of the few
+    # reads in high-copy repeats) are paid once per step instead of three times; three steps in flight: 6.6 M, four do not fit the 288 GB beside
+    # the 69 GB k-mer table: a 1 M-pair batch holds ~45 GB of work memory).
+    if args.chunk_pairs <= 0:
+        args.chunk_pairs = wl.get("chunk_pairs", 1_001_000)
+    if args.depth <= 0:
+        args.depth = wl.get("depth", 2 if args.chunk_pairs >= n_barcodes * ppb else 1)
     genome_len = int(sum(wl["lens"]))       # primary contigs; ALT / decoy contigs come on top (index_bytes_in_files has the whole index)
     SEED0 = wl["seed"]
     setup = {}
@@ -459,7 +469,7 @@ def main():
             packed = [shard.pack(seqs_all, lens_all, po_all, flags_all, a) for a in assign]
             del sets_all, seqs_all
 
-        state = dict(h=None)
+        state = dict(h=sets[0][0])   # an existing handle takes the received reads (arx_batch_reset_device): no further work memory beside the resident batches
 
         def scatter_step():
             # device-resident payloads (arachne_amd/shard.py: step_device): every peer's transfer posted together, the library reads the received
@@ -585,8 +595,8 @@ def main():
                 avg_ms = kl["ms"] / kl["calls"]
                 # the bytes of the walk the kernel does: the same lookups, each walked to the first row that is a multiple of the
                 # device's sample interval (counted by the restatement for 8; the reference's own walk to every 32nd row beside it)
-                dense = int(os.environ.get("ARX_SA_DENSE", "8"))
-                per_read = ab["locate8"] if dense == 8 else ab["locate"]
+                dense = int(os.environ.get("ARX_SA_DENSE", "4"))
+                per_read = ab["locate4"] if dense == 4 else ab["locate8"] if dense == 8 else ab["locate"]
                 ach = per_read * reads_per_launch / max(avg_ms * 1e-3, 1e-12) / 1e9
                 out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk to the suffix-array sample every %d-th row)" % dense, bound=bound,
                                               achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=per_read,
@@ -728,11 +738,13 @@ def main():
                         b.free()
                 sets, batches = [], []
                 st = e2e.run(ref, files, os.path.join(ed, "out"), pairs_per_batch=max(20000, rs.n_pairs // (2 * k)), bam_threads=8, rec_threads=8,
-                             lib_path=args.lib or api.LIB_PATH)
+                             lib_path=args.lib or api.LIB_PATH, warm_passes=1)
                 out["end_to_end"] = dict(value=st["pairs_per_s"], unit="paired reads/s", pairs=st["pairs"], seconds=round(st["seconds"], 3), workers=k,
                                          fastq_bytes=sum(os.path.getsize(f) for pr in files for f in pr), bam_bytes=st.get("bam_bytes"), fastq_write_s=round(t_w, 2),
                                          worker_seconds={kk: round(st[kk], 3) for kk in ("feeder_s", "device_s", "fetch_s", "records_s", "bam_s")},
-                                         note="FASTQ files on disk (plain, barcode-sorted, one pair per worker) -> arx_feeder_next -> arx_batch_reset/run/rfa/post -> "
+                                         warm_passes=st.get("warm_passes", 0),
+                                         note="steady state: the second pass over the files, through the batch handles the first pass created (a handle's first batch pays for its "
+                                              "work memory once); FASTQ files on disk (plain, barcode-sorted, one pair per worker) -> arx_feeder_next -> arx_batch_reset/run/rfa/post -> "
                                               "arx_batch_fetch + rfa_fetch + post_fetch -> arx_recbuf_build (primary record per read) -> arx_bam_write (BGZF level 1, one BAM per "
                                               "worker); wall clock over all workers; worker_seconds are summed over the workers")
                 shutil.rmtree(ed, ignore_errors=True)

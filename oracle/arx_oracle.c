@@ -342,16 +342,18 @@ static inline void set_intv(const index_t *ix, int c, biv_t *ik) /* ref: bwt.h:7
 static uint64_t sa_lookup(const index_t *ix, uint64_t k, ora_counters_t *cnt)
 {
 	uint64_t sa = 0, mask = ix->sa_intv - 1;
-	int64_t steps8 = -1; /* LF steps until the first row that is a multiple of 8: the walk of a sample every 8th row (bench.py roofline_locate) */
+	int64_t steps8 = -1, steps4 = -1; /* LF steps until the first row that is a multiple of 8 / of 4: the walk to a sample every 8th / 4th row (bench.py roofline_locate) */
 	while (k & mask) {
 		uint64_t x = k - (k > ix->primary);
 		if (steps8 < 0 && (k & 7) == 0) steps8 = (int64_t)sa;
+		if (steps4 < 0 && (k & 3) == 0) steps4 = (int64_t)sa;
 		int c = occ_block(ix, x)[8 + ((x & 127) >> 4)] >> ((~x & 15) << 1) & 3;
 		++sa;
 		k = k == ix->primary? 0 : ix->L2[c] + occ1(ix, k, c);
 	}
 	if (steps8 < 0) steps8 = (int64_t)sa;
-	if (cnt) { ++cnt->sa_lookups; cnt->sa_lf_steps += sa; cnt->sa_lf_steps8 += steps8; }
+	if (steps4 < 0) steps4 = (int64_t)sa;
+	if (cnt) { ++cnt->sa_lookups; cnt->sa_lf_steps += sa; cnt->sa_lf_steps8 += steps8; cnt->sa_lf_steps4 += steps4; }
 	return sa + ix->sa[k / ix->sa_intv];
 }
 

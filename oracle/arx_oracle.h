@@ -38,6 +38,7 @@ typedef struct {
 	int64_t extb_same_block, extb_two_block; /* the share spent in backward extensions (the backward sweeps of bwt_smem1a) */
 	int64_t n_smem_calls;                    /* bwt_smem1a calls (first pass + re-seeding) */
 	int64_t sa_lf_steps8;                    /* LF steps of the same lookups up to the first row that is a multiple of 8 */
+	int64_t sa_lf_steps4;                    /* ... of 4 (the product's suffix-array sample since round 3) */
 } ora_counters_t;
 
 #ifdef __cplusplus

@@ -7,6 +7,6 @@ mkdir -p arachne_amd/variants
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -Wno-unused-value -c -O3 $flags arachne_amd/csrc/arx_api.hip -Rpass-analysis=kernel-resource-usage -o /tmp/arx_var_$name.o 2> /tmp/arx_var_$name.log &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/arx_var_$name.o arachne_amd/csrc/arx_cold.o arachne_amd/csrc/arx_feeder.o -o arachne_amd/variants/lib_$name.so -Wl,-rpath,/opt/rocm/lib -lz && echo built $name ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/arx_var_$name.o arachne_amd/csrc/arx_cold.o arachne_amd/csrc/arx_index.o arachne_amd/csrc/arx_feeder.o arachne_amd/csrc/arx_bam.o arachne_amd/csrc/arx_multi.o -o arachne_amd/variants/lib_$name.so -Wl,-rpath,/opt/rocm/lib -lz && echo built $name ) &
 done
 wait
