@@ -551,12 +551,17 @@ public:
 	{
 		const int R = b.n_reads, slots = rt.max_seed_slots() > rt.max_slots() ? rt.max_seed_slots() : rt.max_slots(), list_cap = 2 * (b.max_len + 2); // two forward lists per resident lane (hip_fm_coop.h: FwdProg1)
 		rt.set_seed_read_len(b.max_len);
-		rt.seed_prepare(b.bases, b.base_off, b.lens, R);
 		w.err = rt.template alloc<uint32_t>(4); rt.memset0(w.err, 16);
 		w.counter = rt.template alloc<int32_t>(4);
 		w.intv = rt.template alloc<Biv>((size_t)R * CAP_INTV);
-		w.smem_scr = rt.template alloc<Biv>((size_t)slots * list_cap);
 		w.n_intv = rt.template alloc<int32_t>(R + 1); w.n_occ = rt.template alloc<int32_t>(R + 1); w.occ_off = rt.template alloc<int32_t>(R + 2);
+		// Everything below this mark lives for the seeding passes only -- the interval pool (12 KB per read), the task array, the forward
+		// lists, the packed reads, the third pass's intervals: ~28 GB of a 1 M-pair batch's ~65 GB -- and is handed back to the arena when
+		// the passes are through (the later stages of the same batch bump-allocate over it; stream order makes that safe), so that three
+		// 1 M-pair batches in flight fit beside the index and the k-mer table (round 3).
+		const auto seed_mark = rt.arena_mark();
+		rt.seed_prepare(b.bases, b.base_off, b.lens, R);
+		w.smem_scr = rt.template alloc<Biv>((size_t)slots * list_cap);
 		Biv *strat = rt.template alloc<Biv>((size_t)R * CAP_STRAT);
 		int32_t *n_strat = rt.template alloc<int32_t>(R + 1);
 		// first two passes: forward chains -> backward tasks -> gather + re-seeding tasks -> their forward and backward halves -> gather,
@@ -596,7 +601,8 @@ public:
 		rt.run_seed_strat("seed_strat", R, k3, w.counter);
 		KSeedMerge km{w.intv, w.n_intv, strat, n_strat, w.n_occ, w.err};
 		rt.launch_wide("seed_merge", R, km);
-		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R);
+		int64_t total = rt.exclusive_scan(w.n_occ, w.occ_off, R); // (waits for the stream: the seeding kernels are through)
+		rt.arena_rewind(seed_mark); // HipRT: the seeding passes' memory goes back to the arena (w.smem_scr dangles from here on: nothing reads it); the test double keeps it
 		if (total >= (int64_t)1 << 30) return -2; // keep 32-bit pool indices; the caller splits the batch
 		w.T = total;
 		w.occ_seed = rt.template alloc<Seed>(w.T + 1); w.occ_rid = rt.template alloc<int32_t>(w.T + 1);

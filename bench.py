@@ -294,13 +294,14 @@ def main():
         wl["lens"] = [args.genome_len - 2_000_000, 1_500_000, 500_000] if args.genome_len > 8_000_000 else [args.genome_len]
     n_barcodes, ppb = args.barcodes or wl["barcodes"], args.pairs_per_barcode or wl["ppb"]
     # Batch shape (round 3, measured on the default command: 350 k x 3 batches per step 8.73 M pairs/s, 520 k x 2 with two steps in flight 8.36 M,
-    # ONE 1,001 k batch per step with two steps in flight 8.95-9.13 M -- the one-wavefront tails of a batch (rescue replay, chaining of the few
-    # reads in high-copy repeats) are paid once per step instead of three times; three steps in flight: 6.6 M, four do not fit the 288 GB beside
-    # the 69 GB k-mer table: a 1 M-pair batch holds ~45 GB of work memory).
+    # ONE 1,001 k batch per step with two steps in flight 8.95-9.13 M, with three in flight 9.73 M, with four 8.94 M -- the one-wavefront tails of
+    # a batch (rescue replay, chaining of the few reads in high-copy repeats) are paid once per step instead of three times.  A 1 M-pair batch holds
+    # ~37 GB of work memory since the seeding passes hand theirs back to the arena (65 GB before: three in flight beside the 69 GB k-mer table
+    # ran at 9.07 M, four did not fit).
     if args.chunk_pairs <= 0:
         args.chunk_pairs = wl.get("chunk_pairs", 1_001_000)
     if args.depth <= 0:
-        args.depth = wl.get("depth", 2 if args.chunk_pairs >= n_barcodes * ppb else 1)
+        args.depth = wl.get("depth", 3 if args.chunk_pairs >= n_barcodes * ppb else 1)
     genome_len = int(sum(wl["lens"]))       # primary contigs; ALT / decoy contigs come on top (index_bytes_in_files has the whole index)
     SEED0 = wl["seed"]
     setup = {}
@@ -405,6 +406,17 @@ def main():
                     b.fetch_into(b.out)                   # regions, alignment records, CIGARs, placed candidates with MAPQ back in host memory
         list(pool.map(worker, range(nb * len(sets))))
 
+    # every handle's first run obtains its work memory (hipMalloc of tens of GB: seconds beside a 69 GB k-mer table): part of the set-up like
+    # the upload of the reads, whatever --warmup says
+    t = time.time()
+    for bs in sets:
+        for b in bs:
+            b.run(api.STAGE_ALN)
+            if not args.no_rfa:
+                b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
+                if args.post:
+                    b.post(fetch=False)
+    setup["prime_handles_s"] = round(time.time() - t, 2)
     run_steps(args.warmup)
     ref.kernel_times_reset(True)   # HIP events around every launch on the launch stream, resolved after the timed region
     barrier()
