@@ -117,20 +117,28 @@ template <class RT> struct Context {
 			else { while (K < 16 && ((uint64_t)1 << (2 * (K + 1))) <= ix.seq_len) ++K; }
 			if (K > OPT_MIN_SEED_LEN - 3) K = OPT_MIN_SEED_LEN - 3;
 			while (K >= 4 && ((uint64_t)20 << (2 * K)) > rt.free_bytes() / 3) --K; // 16 bytes per entry, plus the level before it while it is built
-			ix.ktab = nullptr; ix.ktab_k = 0;
+			ix.ktab = nullptr; ix.ktab_k = 0; ix.klv = nullptr; ix.klv_k = 0;
 			if (K >= 4) {
-				uint64_t *prev = nullptr;
+				// levels 1 .. Kf are kept back to back for the forward extensions of the SMEM pass (every depth of a list prefix is needed there:
+				// dev_fm.h FwdLane); Kf = min(K, 14): 5.7 GB.  ARX_KMER_FWD=0: none (the forward kernels walk base by base)
+				const char *ef = getenv("ARX_KMER_FWD");
+				const int Kf = (ef && atoi(ef) == 0) ? 0 : (K < 14 ? K : 14);
+				uint64_t *lv = nullptr;
+				if (Kf > 0) lv = rt.template palloc<uint64_t>(2 * ((((size_t)1 << (2 * (Kf + 1))) - 4) / 3) + 2);
+				uint64_t *prev = nullptr; bool prev_owned = false;
 				for (int d = 0; d < K; ++d) { // level d + 1: 4^(d+1) entries
 					const size_t n_out = (size_t)1 << (2 * (d + 1));
-					uint64_t *out = rt.template palloc<uint64_t>(2 * n_out + 2);
+					const bool in_lv = d + 1 <= Kf;
+					uint64_t *out = in_lv ? lv + 2 * ((n_out - 4) / 3) : rt.template palloc<uint64_t>(2 * n_out + 2);
 					KKmerLevel kk{ix, prev, out, d};
 					rt.launch_wide("kmer_level", d == 0 ? 4 : (int)(n_out >> 2), kk);
 					rt.sync();
-					if (prev) rt.pfree(prev);
-					prev = out;
+					if (prev && prev_owned) rt.pfree(prev);
+					prev = out; prev_owned = !in_lv;
 				}
-				dev_index.push_back(prev);
-				ix.ktab = prev; ix.ktab_k = K;
+				if (prev_owned) dev_index.push_back(prev);
+				if (lv) dev_index.push_back(lv);
+				ix.ktab = prev; ix.ktab_k = K; ix.klv = lv; ix.klv_k = Kf;
 			}
 		}
 		for (auto &n : hix.names) name_ptrs.push_back(n.c_str());

@@ -58,7 +58,10 @@ struct IndexView {
 	int64_t l_pac;
 	int32_t n_seqs, sa_intv;
 	// bi-interval of every ktab_k-mer (dev_fm.h: ktab_*), built when the index is opened; null / 0: none
-	const uint64_t *ktab; int32_t ktab_k, pad_;
+	const uint64_t *ktab; int32_t ktab_k;
+	// ... and of every prefix of it down to one base, for the forward extensions of the SMEM pass (levels 1 .. klv_k back to back, level d at
+	// entry (4^d - 4) / 3); null / 0: none
+	int32_t klv_k; const uint64_t *klv;
 };
 
 struct Biv { uint64_t k, l, s, info; };  // bwtintv_t (bwt.h:59): k = x[0], l = x[1], s = x[2], info = beg<<32|end

@@ -192,6 +192,14 @@ ARX_DEVI Biv ktab_load(const IndexView &ix, uint64_t code)
 	return ktab_unpack(w.a, w.b);
 }
 
+ARX_DEVI Biv klv_load(const IndexView &ix, int d, uint64_t code) // level d (1 .. klv_k), code of the d-mer
+{
+	struct alignas(16) W2 { uint64_t a, b; };
+	const uint64_t at = ((((uint64_t)1 << (2 * d)) - 4) / 3) + code;
+	const W2 w = *(const W2 *)(ix.klv + 2 * at);
+	return ktab_unpack(w.a, w.b);
+}
+
 // one LF step of bwt_invPsi (bwt.c:53-59)
 ARX_DEVI uint64_t lf_step(const IndexView &ix, uint64_t k)
 {
@@ -260,12 +268,37 @@ struct SeedPools { // batch-wide, filled through atomic cursors; an overflow rai
 
 // forward half of bwt_smem1a (bwt.c:299-321) from position x (q[x] is a base): list[] receives the interval each time its
 // size changes, shortest match first
+// With the per-depth k-mer tables (ix.klv; round 3, the wavefront kernels of hip_fm_coop.h only): the intervals of the first K bases are a
+// function of those bases, so an extension whose first K bases are A/C/G/T inside the read takes the interval of the K-mer from the table
+// (start_jump / take_jump: ONE load instead of K - 1 dependent extensions) provided that interval still holds min_intv occurrences --
+// sizes only shrink with depth, so the walk cannot have ended earlier -- and goes on base by base from there.  The list entries the walk
+// would have pushed on the way (depth d whenever the size changes from d to d + 1, bwt.c:308-313) are NOT stored by the lane: n_def says
+// that depths 1 .. n_def are still owed, and the wavefront adds them from the tables when the list is exported to its pool slice
+// (hip_fm_coop.h: persistent_lanes, grant step).
 template <class Q> struct FwdLane {
 	Q q; Biv *list; int len, i, min_intv, n, last_end; bool finished; Biv ik;
+	int n_def, x0; uint32_t code; // owed list prefix (0: none), the start, the code of its first klv_k bases
 	ARX_DEVI void start(const IndexView &ix, int len_, const Q &q_, int x, int min_intv_, Biv *list_)
 	{
-		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false; last_end = 0;
+		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false; last_end = 0; n_def = 0; x0 = x; code = 0;
 		ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1;
+	}
+	// start(), and true if the interval of the first klv_k bases may be asked for (*code_out: its table index); the caller then hands it to take_jump()
+	ARX_DEVI bool start_jump(const IndexView &ix, int len_, const Q &q_, int x, int min_intv_, Biv *list_, uint64_t *code_out)
+	{
+		start(ix, len_, q_, x, min_intv_, list_);
+		const int K = ix.klv_k;
+		if (!ix.klv || x + K > len) return false;
+		uint32_t c = (uint32_t)q.at(x);
+		for (int p = 1; p < K; ++p) { const int b = q.at(x + p); if (b > 3) return false; c |= (uint32_t)b << (2 * p); }
+		code = c; *code_out = c;
+		return true;
+	}
+	ARX_DEVI void take_jump(const IndexView &ix, const Biv &t)
+	{
+		if (t.s < (uint64_t)min_intv) return; // the walk ends inside the first K bases: base by base from the start, as set up by start()
+		const int K = ix.klv_k;
+		ik = t; ik.info = x0 + K; i = x0 + K; n_def = K - 1;
 	}
 	ARX_DEVI bool advance(Biv *req, int *rc)
 	{

@@ -150,18 +150,19 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 	// persistent_lanes()).  (Parking after every extension until 48 lanes had parked left 30 of 64 lanes extending.)
 	static constexpr bool ALLOCATES = true, NEW_TASK = true;
 	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last, cur, pend_n, pend_x, pend_buf; bool extending, awaiting, over;
-	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), cur(0), pend_n(0), pend_x(0), pend_buf(0), extending(false), awaiting(false), over(true) {}
+	int pend_def; uint32_t pend_code; bool want_tab; // the pending list's owed prefix (FwdLane::n_def) and its k-mer; the lane has asked for a table entry
+	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), cur(0), pend_n(0), pend_x(0), pend_buf(0), extending(false), awaiting(false), over(true), pend_def(0), pend_code(0), want_tab(false) {}
 	__device__ Biv *buf(int b) const { return list + b * (A.list_cap >> 1); }
 	__device__ bool begin(int item)
 	{
-		r = A.read0 + item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false; pend_n = 0; cur = 0;
+		r = A.read0 + item; len = A.lens[r]; x = 0; head = last = -1; extending = false; awaiting = false; over = false; pend_n = 0; cur = 0; pend_def = 0; want_tab = false;
 		if (len > MAX_READ_LEN) { atomicOr(A.P.err, ERR_READ_TOO_LONG); len = 0; }
 		if (len < OPT_MIN_SEED_LEN) { A.first1[r] = -1; over = true; return false; }
 		return true;
 	}
 	__device__ void shelve() // the finished list of ln becomes the pending one; the next start is where its longest match ends
 	{
-		pend_n = ln.n; pend_x = x; pend_buf = cur; x = ln.ret(); cur ^= 1; extending = false;
+		pend_n = ln.n; pend_x = x; pend_buf = cur; pend_def = ln.n_def; pend_code = ln.code; x = ln.ret(); cur ^= 1; extending = false;
 	}
 	__device__ bool advance(Biv *req, int *rb, int *rc, bool)
 	{
@@ -174,19 +175,23 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 			}
 			while (x < len && q.at(x) > 3) ++x;
 			if (x >= len) { over = true; break; }
-			ln.start(A.ix, len, q, x, 1, buf(cur));
+			uint64_t code = 0;
 			extending = true;
+			if (ln.start_jump(A.ix, len, q, x, 1, buf(cur), &code)) { want_tab = true; req->k = code; *rc = -1; return true; } // the interval of the first K bases: one table load (consume() below)
 		}
 		return false;
 	}
-	__device__ int want() const { return 3 * pend_n; }
+	__device__ int want() const { return 3 * (pend_n + pend_def); } // an upper bound while a prefix is owed: the depths whose size does not change take no entry
 	__device__ bool parked() const { return awaiting; }
 	__device__ int export_off() const { return (int)(buf(pend_buf) - A.scratch); } // where the list to export lies, in entries from A.scratch
-	__device__ void granted(int off, int t)
+	__device__ int export_def() const { return pend_def; }
+	__device__ uint32_t export_code() const { return pend_code; }
+	__device__ int export_x() const { return pend_x; }
+	__device__ void granted(int off, int t, int n_act) // n_act: entries the wavefront wrote (the lane's own plus the owed prefix)
 	{
-		const int n = pend_n;
-		pend_n = 0;
-		if (t >= A.P.task_cap || (int64_t)off + 3 * n > A.P.pool_cap) {
+		const int n = n_act, n_res = pend_n + pend_def;
+		pend_n = 0; pend_def = 0;
+		if (t >= A.P.task_cap || (int64_t)off + 3 * n_res > A.P.pool_cap) {
 			atomicOr(A.P.err, ERR_POOL_OVERFLOW);
 			if (t < A.P.task_cap) { SeedTask e = SeedTask(); e.read = r; e.next = -1; A.P.tasks[t] = e; } // the id is taken: leave an empty task the later kernels skip
 			over = true; awaiting = false;
@@ -198,7 +203,7 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 		last = t;
 		if (awaiting) { awaiting = false; shelve(); } // the parked second list moves up
 	}
-	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
+	__device__ void consume(const Biv &, const Biv &ok) { if (want_tab) { want_tab = false; ln.take_jump(A.ix, ok); } else ln.consume(ok); }
 	__device__ bool done() const { return over && pend_n == 0; }
 	__device__ void finish() { A.first1[r] = head; }
 };
@@ -227,7 +232,10 @@ struct FwdProg2 { // re-seeding: the forward extension of one task
 	__device__ int want() const { return awaiting ? 3 * ln.n : 0; }
 	__device__ bool parked() const { return awaiting; }
 	__device__ int export_off() const { return (int)(list - A.scratch); }
-	__device__ void granted(int off, int)
+	__device__ int export_def() const { return 0; } // (re-seeding extensions end within a few bases of where a k-mer table would take them: base by base)
+	__device__ uint32_t export_code() const { return 0; }
+	__device__ int export_x() const { return 0; }
+	__device__ void granted(int off, int, int)
 	{
 		awaiting = false; over = true;
 		if ((int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); return; } // n stays 0: the task is skipped
@@ -260,7 +268,10 @@ struct BwdProg { // the backward sweep of one task
 	__device__ int want() const { return 0; }
 	__device__ bool parked() const { return false; }
 	__device__ int export_off() const { return 0; }
-	__device__ void granted(int, int) {}
+	__device__ int export_def() const { return 0; }
+	__device__ uint32_t export_code() const { return 0; }
+	__device__ int export_x() const { return 0; }
+	__device__ void granted(int, int, int) {}
 	__device__ void consume(const Biv &req, const Biv &ok) { ln.consume(req, ok); }
 	__device__ bool done() const { return ln.finished; }
 	__device__ void finish()
@@ -379,11 +390,13 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 				// The finished forward lists go to their pool slices, longest first (bwt.c:322), copied by the whole wavefront: four lists per
 				// step, one per 16-lane quarter (most lists have 16 entries or fewer), their loads in flight together.  A lane copying its own
 				// list waits for a round trip per entry, ~18 of them, with the rest of the wavefront waiting for it.
-				__shared__ int g_n[64], g_off[64], g_src[64];
+				__shared__ int g_n[64], g_off[64], g_src[64], g_def[64], g_x[64], g_act[64];
+				__shared__ uint32_t g_code[64];
 				if (amt > 0) {
-					const int off = base + incl - amt;
-					g_n[rank] = (int64_t)off + amt <= A.P.pool_cap ? amt / 3 : 0; // 0: granted() raises the error, nothing is copied
+					const int off = base + incl - amt, ndef = prog.export_def();
+					g_n[rank] = (int64_t)off + amt <= A.P.pool_cap ? amt / 3 - ndef : -1; // the lane's own entries; -1: granted() raises the error, nothing is copied
 					g_off[rank] = off; g_src[rank] = prog.export_off();
+					g_def[rank] = ndef; g_code[rank] = prog.export_code(); g_x[rank] = prog.export_x();
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_wave_barrier();
@@ -391,14 +404,33 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 				const int n_ask = __builtin_popcountll(askers), quarter = lane >> 4, el = lane & 15;
 				for (int k0 = 0; k0 < n_ask; k0 += 4) {
 					const int k = k0 + quarter;
-					if (k < n_ask) {
-						const int n_a = g_n[k], off_a = g_off[k];
+					const bool live = k < n_ask && g_n[k] >= 0;
+					const int n_a = live ? g_n[k] : 0, off_a = live ? g_off[k] : 0, ndef = live ? g_def[k] : 0;
+					if (live) {
 						const Biv *src = A.scratch + g_src[k];
 						for (int e = el; e < n_a; e += 16) A.P.pool[off_a + e] = src[n_a - 1 - e];
 					}
+					// The list prefix the lane did not store (dev_fm.h FwdLane): depth d = el + 1 of this list's k-mer from the tables, all depths of the
+					// four lists side by side; depth d takes an entry where the size changes from d to d + 1 (bwt.c:308-313), the entries follow the lane's
+					// own in order of decreasing depth ("longest first", bwt.c:322)
+					int n_pre = 0;
+					if (__ballot(ndef > 0)) { // (wave-uniform)
+						const int d = el + 1;
+						Biv td = Biv();
+						if (ndef > 0 && d <= ndef + 1) td = klv_load(A.ix, d, (uint64_t)(g_code[k] & (uint32_t)((1ull << (2 * d)) - 1ull)));
+						const uint64_t s_next = shfl_u64(td.s, (lane & 48) | ((el + 1) & 15)); // the size at depth d + 1, from the lane beside
+						const bool flag = ndef > 0 && d <= ndef && td.s != s_next;
+						const unsigned m16 = (unsigned)(__ballot(flag) >> (lane & 48)) & 0xffffu;
+						n_pre = __builtin_popcount(m16);
+						if (flag) { td.info = (uint64_t)(g_x[k] + d); A.P.pool[off_a + n_a + __builtin_popcount(m16 >> (el + 1))] = td; }
+					}
+					if (live && el == 0) g_act[k] = n_a + n_pre;
 				}
-				__builtin_amdgcn_wave_barrier(); // the LDS words are rewritten by the next grant step
-				if (amt > 0) prog.granted(base + incl - amt, tbase + rank);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_wave_barrier(); // (g_act is read below; the LDS words are rewritten by the next grant step)
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				if (amt > 0) prog.granted(base + incl - amt, tbase + rank, g_n[rank] >= 0 ? g_act[rank] : 0);
+				__builtin_amdgcn_wave_barrier();
 			}
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // a lane whose parked list just got its slice goes on
 		}
@@ -410,7 +442,13 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
 		}
-		if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
+		if (Prog::NEW_TASK && A.ix.klv) { // first pass with k-mer tables: a lane that starts an extension asks for ONE table entry (rc < 0) where the
+			// others ask for an extension; the table load of every lane (entry 0 for those that do not want one: a cached line) is issued ahead of
+			// the Occ loads, so that one wait covers both kinds
+			const bool is_tab = have_req && rc < 0;
+			const Biv tab = klv_load(A.ix, A.ix.klv_k, is_tab ? req.k : 0);
+			if (have_req) { Biv ok = tab; if (!is_tab) ok = extend1(A.ix, req, rb, rc); prog.consume(req, ok); have_req = false; }
+		} else if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}
 	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 2, n_slow); atomicAdd(A.dbg + 3, 1ull); }
 }

@@ -236,8 +236,8 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="grch38", choices=sorted(WORKLOADS), help="grch38: the configuration the metric is quoted on (default); chr20: configs[1]; alt_repeat: configs[3]; vxmix: configs[4]")
     ap.add_argument("--barcodes", type=int, default=0, help="override the workload's barcodes per step")
     ap.add_argument("--pairs-per-barcode", type=int, default=0, help="override the workload's pairs per barcode")
