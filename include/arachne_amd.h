@@ -52,10 +52,15 @@ typedef struct { int64_t pos; int32_t rid, n, seed_off, w, kept, first, is_alt, 
 typedef struct { int64_t rbeg; int32_t qbeg, len; } arx_seed;                                                         /* mem_seed_t  */
 
 /* Builds <prefix>.{bwt,sa,pac,ann,amb} from a plain-text FASTA, byte-identical to the reference's `bwa index`
- * (bwa/bwtindex.c:251-316 bwa_idx_build); host-side, needs no GPU.  msg (may be NULL) receives the error text. */
+ * (bwa/bwtindex.c:251-316 bwa_idx_build).  FASTA parsing and the .pac / .ann / .amb files are host work; BWT and suffix array are sorted
+ * in HBM when a HIP device is visible (any genome size the HBM holds: GRCh38 in ~10 s) and by a 32-bit host sorter otherwise (2 * l_pac < 2^31;
+ * ARX_INDEX_HOST=1 forces it, ARX_INDEX_DEVICE=k picks the device) -- same bytes either way.  msg (may be NULL) receives the error text. */
 int arx_index_build(const char *fasta, const char *prefix, char *msg, int32_t msg_cap);
 
-/* Loads <prefix>.{bwt,sa,pac,ann,amb,alt} (files written by `bwa index`) into HBM of `device`. */
+/* Loads <prefix>.{bwt,sa,pac,ann,amb,alt} (files written by `bwa index`) into HBM of `device`; derives there, once, what the kernels use
+ * beside the files' content: the Occ blocks re-packed for one popcount per count, the suffix-array sample every 4th row (ARX_SA_DENSE), the
+ * k-mer tables of the seeding passes (ARX_KMER_K / ARX_KMER_FWD: up to 69 GB + 5.7 GB at GRCh38 size, never more than a third of the free
+ * memory).  ~4 s for GRCh38. */
 int arx_open(const char *prefix, int device, arx_ctx **out);
 void arx_close(arx_ctx *ctx); /* also frees the context's batches that are still alive: their handles are invalid afterwards */
 const char *arx_last_error(arx_ctx *ctx);      /* ctx may be NULL after a failed arx_open */
