@@ -523,6 +523,9 @@ def main():
                                index_bytes_in_files=index_bytes, pairs_per_step_per_gpu=rs.n_pairs, device_batches=len(batches),
                                parallelism=f"barcode-sharded x{world}"))
         out["per_rank"] = per_rank
+        # how often the whole path ran over the read set in this process (profilers sum over all of it): priming of every handle, warm-up, timed
+        # steps, the boundary pass (one sizing step + its steps), the "alone" pass
+        out["whole_path_passes"] = len(sets) + args.warmup + args.steps + (1 + args.boundary_steps if (args.boundary_steps > 0 and args.stagger) else 0) + 1
         out["setup_s"] = setup
         if boundary:
             out_bytes = sum(int(c["n_regs"]) * (88 + 48) + int(c["n_cigar"]) * 4 + int(c["n_reads"]) * 8 for c in counts) + sum(b._n_cands for b in batches) * 96

@@ -81,7 +81,7 @@ try:
     for r in res.get("kernel_stats", []):      # template instances share a short name: sum them
         e = ks_.setdefault(r["kernel"], dict(total_ms=0.0, calls=0))
         e["total_ms"] += r["total_ms"]; e["calls"] += r["calls"]
-    passes = bp["steps"] + bp["warmup"] + 1                  # whole-path passes over the read set in the profiled command (timed + warm-up + the "alone" pass)
+    passes = bp.get("whole_path_passes", bp["steps"] + bp["warmup"] + 1)   # whole-path passes over the read set in the profiled command (priming + warm-up + timed + the "alone" pass)
     reads = 2.0 * bp["config"]["pairs_per_step_per_gpu"]
     groups = {"extend": (["k_extend_g16<4>", "k_extend_g16<7>", "k_extend_g16<10>", "k_extend_g16<16>", "k_extend_classes", "k_extend_b16", "k_extend_classes_b"], "cells_extend"),
               "sw_u8": (["k_sw_u8_g16<10>", "k_sw_u8_g16<16>"], "cells_u8"), "reg2aln_nw": (["k_reg2aln_nw_g16"], "cells_global"),
