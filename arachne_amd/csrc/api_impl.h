@@ -237,7 +237,7 @@ template <class RT> struct Batch {
 		*out = 0;                                                                                                                   \
 		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
 		{ int64_t tot = 0;                                                                                                          \
-		  for (int i = 0; i < n_reads; ++i) { if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; } tot += lens[i]; } \
+		  for (int i = 0; i < n_reads; ++i) { if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 255]"); return ARX_E_ARG; } tot += lens[i]; } \
 		  if (tot >= ((int64_t)1 << 31) - 64) { c->set_error("batch too large: more than 2^31 bases, split the batch"); return ARX_E_TOO_LARGE; } } \
 		ARX_TRY(c, Bat *b = new Bat(c); b->rt.bind(); b->db = b->pipe.upload(bases, lens, n_reads); b->lens_host.assign(lens, lens + n_reads); *out = (arx_batch *)b;) \
 		return ARX_OK;                                                                                                              \
@@ -247,7 +247,7 @@ template <class RT> struct Batch {
 		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
 		if (n_reads <= 0 || (n_reads & 1)) { c->set_error("n_reads must be positive and even (read 2i/2i+1 are mates)"); return ARX_E_ARG; } \
 		{ int64_t tot = 0;                                                                                                          \
-		  for (int i = 0; i < n_reads; ++i) { if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 249]"); return ARX_E_ARG; } tot += lens[i]; } \
+		  for (int i = 0; i < n_reads; ++i) { if (lens[i] < 0 || lens[i] > arx::MAX_READ_LEN) { c->set_error("read length outside [0, 255]"); return ARX_E_ARG; } tot += lens[i]; } \
 		  if (tot >= ((int64_t)1 << 31) - 64) { c->set_error("batch too large: more than 2^31 bases, split the batch"); return ARX_E_TOO_LARGE; } } \
 		ARX_TRY(c, b->rt.bind();                                                                                                    \
 			b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; b->rfa_marked = false;                      \
@@ -265,7 +265,7 @@ template <class RT> struct Batch {
 			b->pipe.free_work(b->work); b->res = arx::BatchResult(); b->done_stage = 0; b->rfa_marked = false;                      \
 			b->rfa = arx::RfaResult(); b->post = arx::PostResult();                                                                 \
 			ok = b->pipe.upload_from_device(b->db, d_bases, d_lens, n_reads, n_bases, 0, b->lens_host);)                            \
-		if (!ok) { c->set_error("device batch: the read lengths do not add up to n_bases, or a length is outside [0, 249]"); return ARX_E_ARG; } \
+		if (!ok) { c->set_error("device batch: the read lengths do not add up to n_bases, or a length is outside [0, 255]"); return ARX_E_ARG; } \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_device_view(arx_ctx *h, arx_batch *bh, arx_device_view *v)                                                        \

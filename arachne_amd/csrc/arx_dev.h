@@ -36,7 +36,8 @@ constexpr int KSW_XBYTE = 0x10000, KSW_XSTOP = 0x20000, KSW_XSUBO = 0x40000, KSW
 // Arachne's fixed insert model: only FR valid, [-35, 500] (/root/reference/src/gobwa/gobwa.go:229-237)
 constexpr int PES_LOW = -35, PES_HIGH = 500, MAX_RESCUE = 50;
 
-constexpr int MAX_READ_LEN = 249;   // u8 rescue SW is only exact below 250 (bwamem_pair.c:150)
+constexpr int MAX_READ_LEN = 255;   // 249 until round 3: mates of 250 bases and more take ksw_i16 (bwamem_pair.c:150, ksw.c:232-334) -- its eight-stripe
+                                    // form of the rescue SW exists since; 255 is what the byte-wide fields and the 16-lane tilings of the DP kernels hold
 // Extensions are binned by query length so that a wavefront's four 16-lane groups run the same register tiling
 // (hip_sw_coop.h: C columns per lane, 16 * C > qlen; C = 2, 3, 4, 6, 8, 10, 16)
 constexpr int EXT_CLASSES = 7;

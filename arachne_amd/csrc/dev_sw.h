@@ -112,12 +112,17 @@ struct PrefixRevView { // element i of a sequence whose first n_rev elements are
 ARX_DEVI int sat_add8(int a, int b) { int s = a + b; return s > 255 ? 255 : s; }
 ARX_DEVI int sat_sub8(int a, int b) { return a > b ? a - b : 0; }
 
-// one ksw_u8 pass; rowmax (>= tlen bytes) records the per-row maxima for the score2/te2 scan
-ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax)
+// one ksw_u8 pass; rowmax (>= tlen bytes) records the per-row maxima for the score2/te2 scan.
+// i16 = true: the same pass as ksw_i16 runs it (ksw.c:232-334; ksw_align2 takes it when the caller did not set KSW_XBYTE, i.e. for mates
+// of 250 bases and more, bwamem_pair.c:150): EIGHT stripes instead of sixteen, no bias, no 255 ceiling.  Everything else is the same
+// arithmetic -- adds_epi16(h, s) followed by the maxima with e, f >= 0 is max(h + s, 0) like the biased byte form, the gap states use the
+// same unsigned saturating subtractions -- and for reads of up to 255 bases every value still fits the byte fields of the row word.
+ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax, bool i16 = false)
 {
 	const int shift = 4, qmax = 1; // ksw_qinit: shift = 256 - (uint8_t)min(mat) = 4, max = 1
 	const int oe_del = OPT_O_DEL + OPT_E_DEL, e_del = OPT_E_DEL, oe_ins = OPT_O_INS + OPT_E_INS, e_ins = OPT_E_INS;
-	const int slen = (qlen + 15) >> 4, n16 = slen * 16;
+	const int NS = i16 ? 8 : 16;
+	const int slen = (qlen + NS - 1) / NS, n16 = slen * NS;
 	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000, endsc = (xtra & KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
 	int i, j, l, te = -1, gmax = 0, cur = 0, rows = 0;
 	for (i = 0; i < n16; ++i) row[i * stride] = 0;
@@ -127,15 +132,15 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 		int imax = 0;
 		int fl[16]; // F carried across the lazy loop, one per stripe
 		// main pass: each stripe is an independent chain over its slen consecutive query positions
-		for (l = 0; l < 16; ++l) {
+		for (l = 0; l < NS; ++l) {
 			int f = 0, mx = 0;
-			int h = l == 0 ? 0 : (int)((row[((slen - 1) * 16 + l - 1) * stride] >> sh_prev) & 0xff); // H(i-1) of the previous stripe's last cell
+			int h = l == 0 ? 0 : (int)((row[((slen - 1) * NS + l - 1) * stride] >> sh_prev) & 0xff); // H(i-1) of the previous stripe's last cell
 			for (j = 0; j < slen; ++j) {
 				const int k = j + l * slen;
-				uint32_t wd = row[(j * 16 + l) * stride];
+				uint32_t wd = row[(j * NS + l) * stride];
 				int e = (wd >> 16) & 0xff, tt;
 				int sc = (k >= qlen ? 0 : sc_mat(tb, q[k])) + shift;
-				int hh = sat_sub8(sat_add8(h, sc), shift);
+				int hh = i16 ? h + sc - shift : sat_sub8(sat_add8(h, sc), shift); // (16-bit lanes do not saturate at 255: a 255-base mate can score 255)
 				hh = hh > e ? hh : e;
 				hh = hh > f ? hh : f;
 				mx = mx > hh ? mx : hh;
@@ -143,7 +148,7 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 				e = sat_sub8(e, e_del); tt = sat_sub8(hh, oe_del); e = e > tt ? e : tt;
 				f = sat_sub8(f, e_ins); tt = sat_sub8(hh, oe_ins); f = f > tt ? f : tt;
 				wd = (wd & ~(0xffu << sh_new) & ~(0xffu << 16)) | (uint32_t)hh << sh_new | (uint32_t)e << 16;
-				row[(j * 16 + l) * stride] = wd;
+				row[(j * NS + l) * stride] = wd;
 			}
 			fl[l] = f;
 			imax = imax > mx ? imax : mx;
@@ -152,14 +157,14 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 		{
 			bool done = false;
 			for (int k2 = 0; k2 < 16 && !done; ++k2) {
-				for (l = 15; l > 0; --l) fl[l] = fl[l - 1];
+				for (l = NS - 1; l > 0; --l) fl[l] = fl[l - 1];
 				fl[0] = 0;
 				for (j = 0; j < slen; ++j) {
 					bool all = true;
-					for (l = 0; l < 16; ++l) {
-						uint32_t wd = row[(j * 16 + l) * stride];
+					for (l = 0; l < NS; ++l) {
+						uint32_t wd = row[(j * NS + l) * stride];
 						int hh = (wd >> sh_new) & 0xff;
-						if (fl[l] > hh) { hh = fl[l]; row[(j * 16 + l) * stride] = (wd & ~(0xffu << sh_new)) | (uint32_t)hh << sh_new; }
+						if (fl[l] > hh) { hh = fl[l]; row[(j * NS + l) * stride] = (wd & ~(0xffu << sh_new)) | (uint32_t)hh << sh_new; }
 						hh = sat_sub8(hh, oe_ins);
 						fl[l] = sat_sub8(fl[l], e_ins);
 						if (fl[l] > hh) all = false;
@@ -172,16 +177,16 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 		if (imax > gmax) {
 			gmax = imax; te = i;
 			for (j = 0; j < n16; ++j) { uint32_t wd = row[j * stride]; row[j * stride] = (wd & 0x00ffffffu) | ((wd >> sh_new) & 0xff) << 24; }
-			if (gmax + shift >= 255 || gmax >= endsc) break;
+			if ((!i16 && gmax + shift >= 255) || gmax >= endsc) break;
 		}
 		cur ^= 1;
 	}
 	U8Res r;
-	r.score = gmax + shift < 255 ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
-	if (r.score != 255) {
+	r.score = (i16 || gmax + shift < 255) ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
+	if (i16 || r.score != 255) {
 		int mx = -1;
 		for (i = 0; i < n16; ++i) { // smallest query index attaining the maximum of the saved row (ksw.c:212-216)
-			int v = row[i * stride] >> 24, qpos = i / 16 + i % 16 * slen;
+			int v = row[i * stride] >> 24, qpos = i / NS + i % NS * slen;
 			if (v > mx) { mx = v; r.qe = qpos; }
 			else if (v == mx && qpos < r.qe) r.qe = qpos;
 		}
@@ -243,10 +248,11 @@ ARX_DEVI bool sw_prefilter_serial(const uint8_t *q, int qlen, const uint8_t *t, 
 ARX_DEV U8Res u8_align(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax)
 {
 	PrefixRevView q{query, 0}, t{target, 0};
-	U8Res r = u8_pass(q, qlen, t, tlen, xtra, row, stride, rowmax);
+	const bool i16 = !(xtra & KSW_XBYTE); // ksw_align2's choice of element size (ksw.c:350-353); the second pass keeps it
+	U8Res r = u8_pass(q, qlen, t, tlen, xtra, row, stride, rowmax, i16);
 	if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
 	PrefixRevView q2{query, r.qe + 1}, t2{target, r.te + 1};
-	U8Res rr = u8_pass(q2, r.qe + 1, t2, tlen, KSW_XSTOP | r.score, row, stride, rowmax);
+	U8Res rr = u8_pass(q2, r.qe + 1, t2, tlen, KSW_XSTOP | r.score, row, stride, rowmax, i16);
 	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
 	return r;
 }

@@ -320,7 +320,8 @@ struct HipRT {
 		{
 			Scope sc(*this, nm, n);
 			if (max_len <= 160) hipLaunchKernelGGL(k_sw_u8_g16<10>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order);
-			else hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order);
+			else if (max_len * OPT_A < 250) hipLaunchKernelGGL(k_sw_u8_g16<16>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order);
+			else hipLaunchKernelGGL(k_sw_u8_g16<32>, dim3(blocks), dim3(64), 0, stream, f.ix, f.bases, f.base_off, f.lens, f.tasks, f.res, n, order, n_order); // mates of 250+ bases: ksw_i16's eight stripes of up to 32 cells; shorter mates of the same batch take the byte form inside
 			ARX_HIP_CHECK(hipGetLastError());
 		}
 		if (sw_filter_stats) { int32_t k = 0; d2h(&k, n_order, 4); sw_tasks_seen += n; sw_tasks_run += k; }

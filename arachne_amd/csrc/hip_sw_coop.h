@@ -72,18 +72,21 @@ struct SwSeqs { // how the two passes read their sequences without materialising
 
 // one ksw_u8 pass by a 16-lane group; every lane returns the same U8Res (score2/te2 only valid in lane 0 of the group)
 // FULL: the query fills all SL stripes (slen == SL, e.g. 150 bases at SL = 10), which makes every stripe test a constant
-template <int SL, bool FULL>
+// I16: the pass as ksw_i16 runs it (ksw.c:232-334, mates of 250 bases and more): EIGHT stripes -- lanes 8..15 of the group stay zero: what
+// lane 8 would receive from lane 7 through the shifts is masked --, no 255 ceiling; the arithmetic is the byte form's (dev_sw.h: u8_pass).
+template <int SL, bool FULL, bool I16 = false>
 __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
 {
 	const int l = __lane_id() & 15;
-	const int slen = FULL ? SL : (qlen + 15) >> 4;
+	const bool lane_on = !I16 || l < 8;
+	const int slen = FULL ? SL : (I16 ? (qlen + 7) >> 3 : (qlen + 15) >> 4);
 	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000, endsc = (xtra & KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
 	int H0[SL], H1[SL], E[SL], HM[SL], Q4[SL];
 #pragma unroll
 	for (int j = 0; j < SL; ++j) {
 		const int k = j + l * slen;
 		H0[j] = H1[j] = E[j] = HM[j] = 0;
-		Q4[j] = 4 * ((j < slen && k < qlen) ? sq.q(k) : 5);
+		Q4[j] = 4 * ((j < slen && k < qlen && lane_on) ? sq.q(k) : 5);
 	}
 	int gmax = 0, te = -1, hlast = 0, rows = 0;
 	// one row: reads the previous row's H from Hin, leaves this row's in Hout; the caller alternates the two arrays so that no
@@ -91,6 +94,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 	auto row = [&](const int (&Hin)[SL], int (&Hout)[SL], int i) __attribute__((always_inline)) -> bool {
 		const uint32_t W = u8_score_word(sq.t(i));
 		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
+		if (I16) h = lane_on ? h : 0;
 		// straight-line select code over all SL stripes: stripes past slen (a shorter query in the second pass) come last in
 		// the chain, so what they compute flows nowhere as long as they leave f and the row maximum alone.
 		// _mm_adds_epu8(h, profile) cannot saturate (h <= 249 for reads below 250 bases, profile <= 5), and the floor of
@@ -119,6 +123,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		{
 			bool stop;
 			f = g16_shift_up(f, l);
+			if (I16) f = lane_on ? f : 0;
 			{
 				const int hh = Hout[0] > f ? Hout[0] : f;
 				Hout[0] = hh;
@@ -128,7 +133,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 			}
 			if (!stop) {
 				for (int k2 = 0; k2 < 16 && !stop; ++k2) {
-					if (k2) f = g16_shift_up(f, l);
+					if (k2) { f = g16_shift_up(f, l); if (I16) f = lane_on ? f : 0; }
 #pragma unroll
 					for (int j = 0; j < SL; ++j) {
 						if (j < slen && !stop && (k2 || j)) {
@@ -152,7 +157,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 			gmax = imax; te = i;
 #pragma unroll
 			for (int j = 0; j < SL; ++j) HM[j] = Hout[j];
-			if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
+			if ((!I16 && gmax + 4 >= 255) || gmax >= endsc) brk = true;
 		}
 #pragma unroll
 		for (int j = 0; j < SL; ++j) if (j == slen - 1) hlast = Hout[j];
@@ -163,8 +168,8 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		if (i + 1 < tlen && row(H1, H0, i + 1)) break;
 	}
 	U8Res r;
-	r.score = gmax + 4 < 255 ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
-	if (r.score != 255) {
+	r.score = (I16 || gmax + 4 < 255) ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
+	if (I16 || r.score != 255) {
 		int bv = -1, bq = 0x7fffffff; // this lane's best saved value and the smallest query position holding it
 #pragma unroll
 		for (int j = 0; j < SL; ++j) {
@@ -197,6 +202,11 @@ __device__ __forceinline__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int 
 {
 	return ((qlen + 15) >> 4) == SL ? sw_u8_pass_g16_impl<SL, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_g16_impl<SL, false>(sq, qlen, tlen, xtra, rowmax);
 }
+template <int SL>
+__device__ __forceinline__ U8Res sw_i16_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
+{
+	return sw_u8_pass_g16_impl<SL, false, true>(sq, qlen, tlen, xtra, rowmax);
+}
 
 // one rescue alignment per 16-lane group: forward pass, then the pass over the reversed prefixes (ksw.c:343-365)
 // the target window into LDS, two bases per byte (a per-row load of the reference base would put HBM latency on every row)
@@ -211,17 +221,18 @@ __device__ __forceinline__ void sw_stage_target(const IndexView &ix, int64_t rb,
 template <int SL>
 __device__ void sw_u8_align_g16(const IndexView &ix, const uint8_t *mate, int l_ms, int64_t rb, int tlen, uint8_t *rowmax, uint8_t *tl, U8Res *out)
 {
-	const int xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
+	const bool i16 = SL >= 32 && l_ms * OPT_A >= 250; // bwamem_pair.c:150: KSW_XBYTE only below 250; the SL = 32 instantiation serves the batches that hold such mates
+	const int xtra = KSW_XSUBO | KSW_XSTART | (i16 ? 0 : KSW_XBYTE) | (OPT_MIN_SEED_LEN * OPT_A);
 	// a per-row load of the reference base would put HBM latency on the critical path of every row: fetch the window once
 	sw_stage_target(ix, rb, tlen, tl);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	SwSeqs sq{mate, l_ms, tl, 0, 0};
-	U8Res r = sw_u8_pass_g16<SL>(sq, l_ms, tlen, xtra, rowmax);
+	U8Res r = i16 ? sw_i16_pass_g16<SL>(sq, l_ms, tlen, xtra, rowmax) : sw_u8_pass_g16<SL>(sq, l_ms, tlen, xtra, rowmax);
 	if (!(r.score < (xtra & 0xffff))) {
 		SwSeqs s2{mate, l_ms, tl, r.qe + 1, r.te + 1};
-		U8Res rr = sw_u8_pass_g16<SL>(s2, r.qe + 1, tlen, KSW_XSTOP | r.score, rowmax);
+		U8Res rr = i16 ? sw_i16_pass_g16<SL>(s2, r.qe + 1, tlen, KSW_XSTOP | r.score, rowmax) : sw_u8_pass_g16<SL>(s2, r.qe + 1, tlen, KSW_XSTOP | r.score, rowmax); // the second pass keeps the element size (ksw.c:358)
 		if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
 	}
 	if ((__lane_id() & 15) == 0) *out = r;

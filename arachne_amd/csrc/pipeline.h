@@ -379,7 +379,7 @@ struct KSwU8 {
 		const uint8_t *ms = bases + base_off[r];
 		for (int k = 0; k < l_ms; ++k) { int b = ms[k]; qbuf[l_ms - 1 - k] = b < 4 ? 3 - b : 4; } // reverse complement of the mate (bwamem_pair.c:134-137)
 		for (int k = 0; k < tlen; ++k) tbuf[k] = (uint8_t)ref_base(ix, t.rb + k);
-		res[t.slot] = u8_align(qbuf, l_ms, tbuf, tlen, KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A), row, stride, rowmax);
+		res[t.slot] = u8_align(qbuf, l_ms, tbuf, tlen, KSW_XSUBO | KSW_XSTART | (l_ms * OPT_A < 250 ? KSW_XBYTE : 0) | (OPT_MIN_SEED_LEN * OPT_A), row, stride, rowmax); // bwamem_pair.c:150
 		ARX_SW_FILTER_CHECK(sw_prefilter_serial(qbuf, l_ms, tbuf, tlen), res[t.slot].score);
 	}
 };
@@ -460,6 +460,7 @@ public:
 	IndexView ix;
 	bool trace = getenv("ARX_TRACE") != nullptr; // per-round progress on stderr
 	int seed_group_reads = getenv("ARX_SEED_GROUP") ? atoi(getenv("ARX_SEED_GROUP")) : 0; // reads per pass through the first two seeding passes (0: the whole batch at once; groups shrink the interval pool from 12 KB to 12 KB x group / batch per read at the price of under-filled forward launches: 0 / 360 k / 180 k / 90 k reads -> 7.0 / 9.5 / 11.4 / 14.1 ms of seed_fwd per 667 k-read batch, seed_bwd unchanged)
+	int seed_tasks_per_read = getenv("ARX_SEED_TASKS") ? atoi(getenv("ARX_SEED_TASKS")) : 12;   // seeding tasks per read (all three passes), same rule
 	int seed_pool_per_read = getenv("ARX_SEED_POOL") ? atoi(getenv("ARX_SEED_POOL")) : 384; // interval-pool entries per read (3 per forward-list entry); an overflow is reported, never silent
 	explicit Pipeline(RT &rt_, const IndexView &ix_) : rt(rt_), ix(ix_) {}
 
@@ -572,7 +573,10 @@ public:
 		const int GR = seed_group_reads > 0 ? seed_group_reads : R;
 		const int Rg_max = GR < R ? GR : R;
 		SeedPools P;
-		P.pool_cap = (int64_t)Rg_max * seed_pool_per_read; P.task_cap = (int32_t)((int64_t)Rg_max * 12 < 0x7fffffff ? Rg_max * 12 : 0x7fffffff);
+		// per read, on average: 12 tasks and seed_pool_per_read pool entries for reads of up to 150 bases, in proportion for longer ones
+		// (a 255-base read that matches nowhere yields a first-pass task every ~12 bases on a small genome); an overflow is reported
+		const int64_t len_scale = b.max_len > 150 ? (b.max_len + 149) / 150 : 1, tasks_per_read = (int64_t)seed_tasks_per_read * len_scale;
+		P.pool_cap = (int64_t)Rg_max * seed_pool_per_read * len_scale; P.task_cap = (int32_t)(Rg_max * tasks_per_read < 0x7fffffff ? Rg_max * tasks_per_read : 0x7fffffff);
 		P.pool = rt.template alloc<Biv>((size_t)P.pool_cap + 1); P.tasks = rt.template alloc<SeedTask>((size_t)P.task_cap + 1);
 		P.cursors = rt.template alloc<int32_t>(2); P.err = w.err;
 		int32_t *first1 = rt.template alloc<int32_t>(R + 1), *first2 = rt.template alloc<int32_t>(R + 1);

@@ -1099,13 +1099,146 @@ static kswr_t ksw_u8(u8prof_t *q, int tlen, const uint8_t *target, int xtra, ora
 	return r;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * Striped i16 local Smith-Waterman: what ksw_align2 dispatches to when the query is too long for the byte kernel
+ * (bwamem_pair.c:150: KSW_XBYTE only while l_ms * a < 250).  ref: ksw.c:63-109 (ksw_qinit, size 2), :232-334 (ksw_i16).
+ * Eight signed 16-bit lanes: query position j + lane * slen in vector j, lane `lane`; no bias, no saturation in reach
+ * (scores stay far below 2^15), the gap states' subtractions are the unsigned saturating ones of the original.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int qlen, slen, max; int16_t *qp, *H0, *H1, *E, *Hmax; } i16prof_t;
+static i16prof_t *i16_qinit(int qlen, const uint8_t *query)
+{
+	i16prof_t *q = (i16prof_t*)calloc(1, sizeof(i16prof_t));
+	int slen = (qlen + 7) / 8, a, i, k, hi = 0;
+	int16_t *t;
+	q->qlen = qlen; q->slen = slen;
+	q->qp = (int16_t*)malloc(sizeof(int16_t) * 8 * (size_t)slen * 9);
+	q->H0 = q->qp + 8 * slen * 5; q->H1 = q->H0 + 8 * slen; q->E = q->H1 + 8 * slen; q->Hmax = q->E + 8 * slen;
+	for (a = 0; a < 25; ++a) if (g_mat[a] > hi) hi = g_mat[a];
+	q->max = hi;
+	t = q->qp;
+	for (a = 0; a < 5; ++a) {
+		int nlen = slen * 8;
+		const int8_t *ma = g_mat + a * 5;
+		for (i = 0; i < slen; ++i)
+			for (k = i; k < nlen; k += slen)
+				*t++ = (int16_t)(k >= qlen? 0 : ma[query[k]]);
+	}
+	return q;
+}
+static void i16_free(i16prof_t *q) { free(q->qp); free(q); }
+static inline int16_t subs_u16(int16_t a, int b) { int x = (uint16_t)a; x -= b; return (int16_t)(x > 0? x : 0); } /* _mm_subs_epu16 */
+static inline int16_t adds_i16(int16_t a, int16_t b) { int x = a + b; return (int16_t)(x > 32767? 32767 : x < -32768? -32768 : x); } /* _mm_adds_epi16 */
+
+static kswr_t ksw_i16(i16prof_t *q, int tlen, const uint8_t *target, int xtra, ora_counters_t *cnt)
+{
+	const int oe_del = OPT_O_DEL + OPT_E_DEL, e_del = OPT_E_DEL, oe_ins = OPT_O_INS + OPT_E_INS, e_ins = OPT_E_INS;
+	int slen = q->slen, i, j, k, l, n_b = 0, m_b = 0, te = -1, gmax = 0, minsc, endsc;
+	uint64_t *b = 0;
+	int16_t *H0 = q->H0, *H1 = q->H1, *E = q->E, *Hmax = q->Hmax, *S;
+	kswr_t r = { 0, -1, -1, -1, -1, -1, -1 };
+	int64_t rows = 0;
+	minsc = (xtra & KSW_XSUBO)? xtra & 0xffff : 0x10000;
+	endsc = (xtra & KSW_XSTOP)? xtra & 0xffff : 0x10000;
+	memset(E, 0, 16 * slen); memset(H0, 0, 16 * slen); memset(Hmax, 0, 16 * slen);
+	for (i = 0; i < tlen; ++i) {
+		int16_t e, h[8], f[8], mx[8], t;
+		int imax, done;
+		const int16_t *prof = q->qp + (size_t)target[i] * slen * 8;
+		++rows;
+		memset(f, 0, sizeof f); memset(mx, 0, sizeof mx);
+		h[0] = 0;
+		for (l = 1; l < 8; ++l) h[l] = H0[(slen - 1) * 8 + l - 1]; /* H(i-1, last vector) shifted by one lane */
+		for (j = 0; j < slen; ++j) {
+			for (l = 0; l < 8; ++l) {
+				int16_t hh = adds_i16(h[l], prof[j * 8 + l]);
+				e = E[j * 8 + l];
+				hh = hh > e? hh : e;
+				hh = hh > f[l]? hh : f[l];
+				mx[l] = mx[l] > hh? mx[l] : hh;
+				H1[j * 8 + l] = hh;
+				e = subs_u16(e, e_del); t = subs_u16(hh, oe_del);
+				E[j * 8 + l] = e > t? e : t;
+				f[l] = subs_u16(f[l], e_ins); t = subs_u16(hh, oe_ins);
+				f[l] = f[l] > t? f[l] : t;
+				h[l] = H0[j * 8 + l];
+			}
+		}
+		/* lazy-F: the original loops k < 16 here as well (ksw.c:283), with eight lanes */
+		for (k = 0, done = 0; k < 16 && !done; ++k) {
+			for (l = 7; l > 0; --l) f[l] = f[l - 1];
+			f[0] = 0;
+			for (j = 0; j < slen; ++j) {
+				int all = 1;
+				for (l = 0; l < 8; ++l) {
+					int16_t hh = H1[j * 8 + l];
+					hh = hh > f[l]? hh : f[l];
+					H1[j * 8 + l] = hh;
+					hh = subs_u16(hh, oe_ins);
+					f[l] = subs_u16(f[l], e_ins);
+					if (f[l] > hh) all = 0; /* _mm_cmpgt_epi16 */
+				}
+				if (all) { done = 1; break; }
+			}
+		}
+		for (l = 0, imax = 0; l < 8; ++l) imax = imax > mx[l]? imax : mx[l];
+		if (imax >= minsc) {
+			if (n_b == 0 || (int32_t)b[n_b - 1] + 1 != i) {
+				if (n_b == m_b) { m_b = m_b? m_b << 1 : 8; b = (uint64_t*)realloc(b, 8 * m_b); }
+				b[n_b++] = (uint64_t)imax << 32 | i;
+			} else if ((int)(b[n_b - 1] >> 32) < imax) b[n_b - 1] = (uint64_t)imax << 32 | i;
+		}
+		if (imax > gmax) {
+			gmax = imax; te = i;
+			memcpy(Hmax, H1, 16 * slen);
+			if (gmax >= endsc) break;
+		}
+		S = H1; H1 = H0; H0 = S;
+	}
+	if (cnt) { cnt->cells_u8 += rows * slen * 8; ++cnt->n_u8_calls; }
+	r.score = gmax; r.te = te;
+	{
+		int max = -1, tmp, low, high, qlen = slen * 8;
+		for (i = 0; i < qlen; ++i) {
+			int v = (uint16_t)Hmax[i];
+			if (v > max) { max = v; r.qe = i / 8 + i % 8 * slen; }
+			else if (v == max && (tmp = i / 8 + i % 8 * slen) < r.qe) r.qe = tmp;
+		}
+		if (b) {
+			i = (r.score + q->max - 1) / q->max;
+			low = te - i; high = te + i;
+			for (i = 0; i < n_b; ++i) {
+				int e2 = (int32_t)b[i];
+				if ((e2 < low || e2 > high) && (int)(b[i] >> 32) > r.score2) { r.score2 = (int)(b[i] >> 32); r.te2 = e2; }
+			}
+		}
+	}
+	free(b);
+	return r;
+}
+
 static void revseq(int l, uint8_t *s) { int i; for (i = 0; i < l >> 1; ++i) { uint8_t t = s[i]; s[i] = s[l - 1 - i]; s[l - 1 - i] = t; } }
 
 /* ref: ksw.c:343-365.  query/target are scratch copies (reversed in place and restored) */
 static kswr_t ksw_align2_u8(int qlen, uint8_t *query, int tlen, uint8_t *target, int xtra, ora_counters_t *cnt)
 {
-	u8prof_t *q = u8_qinit(qlen, query);
+	u8prof_t *q;
 	kswr_t r, rr;
+	if (!(xtra & KSW_XBYTE)) { /* ksw_align2's dispatch on the element size (ksw.c:350-353); the second pass keeps the size of the first */
+		i16prof_t *p = i16_qinit(qlen, query);
+		r = ksw_i16(p, tlen, target, xtra, cnt);
+		i16_free(p);
+		if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
+		revseq(r.qe + 1, query); revseq(r.te + 1, target);
+		p = i16_qinit(r.qe + 1, query);
+		rr = ksw_i16(p, tlen, target, KSW_XSTOP | r.score, cnt);
+		revseq(r.qe + 1, query); revseq(r.te + 1, target);
+		i16_free(p);
+		if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+		return r;
+	}
+	q = u8_qinit(qlen, query);
 	r = ksw_u8(q, tlen, target, xtra, cnt);
 	u8_free(q);
 	if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
@@ -1118,13 +1251,23 @@ static kswr_t ksw_align2_u8(int qlen, uint8_t *query, int tlen, uint8_t *target,
 	return r;
 }
 
+void ora_ksw_align2_i16(ora_ctx_t *c, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int xtra, int *out) /* the 16-bit kernel whatever the length (known-answer tests) */
+{
+	uint8_t *qq = (uint8_t*)malloc(qlen + 1), *tt = (uint8_t*)malloc(tlen + 1);
+	kswr_t r;
+	(void)c;
+	memcpy(qq, q, qlen); memcpy(tt, t, tlen);
+	r = ksw_align2_u8(qlen, qq, tlen, tt, xtra & ~KSW_XBYTE, 0);
+	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
+	free(qq); free(tt);
+}
 void ora_ksw_align2(ora_ctx_t *c, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int xtra, int *out)
 {
 	uint8_t *qq = (uint8_t*)malloc(qlen + 1), *tt = (uint8_t*)malloc(tlen + 1);
 	kswr_t r;
 	(void)c;
 	memcpy(qq, q, qlen); memcpy(tt, t, tlen);
-	r = ksw_align2_u8(qlen, qq, tlen, tt, xtra | KSW_XBYTE, 0);
+	r = ksw_align2_u8(qlen, qq, tlen, tt, xtra, 0);
 	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
 	free(qq); free(tt);
 }
@@ -1584,8 +1727,7 @@ static int matesw(const index_t *ix, const reg_t *a, int l_ms, const uint8_t *ms
 			kswr_t aln;
 			reg_t b;
 			int tmp, xtra;
-			if (l_ms * OPT_A >= 250) { fprintf(stderr, "[oracle] mate longer than the u8 SW path allows\n"); abort(); }
-			xtra = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | (OPT_MIN_SEED_LEN * OPT_A);
+			xtra = KSW_XSUBO | KSW_XSTART | (l_ms * OPT_A < 250? KSW_XBYTE : 0) | (OPT_MIN_SEED_LEN * OPT_A); /* bwamem_pair.c:150 */
 			aln = ksw_align2_u8(l_ms, seq, (int)(re - rb), ref, xtra, cnt);
 			memset(&b, 0, sizeof(b));
 			if (aln.score >= OPT_MIN_SEED_LEN && aln.qb >= 0) {

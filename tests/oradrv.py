@@ -127,6 +127,15 @@ class Oracle:
         self.lib.ora_ksw_align2(self.h, len(q), q.ctypes.data, len(t), t.ctypes.data, xtra, out.ctypes.data)
         return out
 
+    def ksw_align2_i16(self, q, t, xtra):
+        """ksw_i16 whatever the flag says (ksw.c:232-334)."""
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        out = np.zeros(7, dtype=np.int32)
+        self.lib.ora_ksw_align2_i16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.ora_ksw_align2_i16(self.h, len(q), q.ctypes.data, len(t), t.ctypes.data, xtra, out.ctypes.data)
+        return out
+
     def ksw_global2(self, q, t, w, cap=1024):
         q = np.ascontiguousarray(q, dtype=np.uint8)
         t = np.ascontiguousarray(t, dtype=np.uint8)

@@ -148,27 +148,48 @@ def test_interval_pool_overflow_is_reported(env, monkeypatch):
     parity.check_final(dev, o.batch(z["reads"][:200], z["lens"][:200]))
 
 
-@pytest.mark.parametrize("read_len", [249, 200, 101])
-def test_other_read_lengths_take_the_wide_kernel_variants(built, read_len):
-    """Reads up to MAX_READ_LEN = 249: the 16-stripe rescue SW, the widest extension class, wide CIGAR bands."""
+@pytest.mark.parametrize("read_len,mixed", [(255, False), (250, False), (250, True), (249, False), (200, False), (101, False)])
+def test_other_read_lengths_take_the_wide_kernel_variants(built, read_len, mixed):
+    """Reads up to MAX_READ_LEN = 255: the widest extension class, wide CIGAR bands, the 16-stripe rescue SW below 250 bases and -- round 3 --
+    ksw_i16's eight stripes from 250 on (ksw_align2 drops KSW_XBYTE there, bwamem_pair.c:150), also in a batch that mixes both; against the
+    restatement AND the compiled reference."""
     import oradrv
+    import refdrv
     import rfadrv
-    from arachne_amd import synth
-    g = synth.make_genome(500 + read_len, [1_200_000])
-    rs = synth.make_reads(501 + read_len, g, 3, 300, read_len=read_len)
+    g, rs, seqs, lens = workloads.long_reads(read_len, mixed=mixed)
     tmp = tempfile.mkdtemp(prefix="arx_gpu_len_")
     prefix = os.path.join(tmp, "g.fa")
     g.write_fasta(prefix)
     api.index_build(prefix, prefix)
     ref = api.load_reference(prefix, 0)
     o = oradrv.Oracle(prefix)
-    b = ref.batch(rs.seqs, rs.lens).run()
-    ora = o.batch(rs.seqs, rs.lens, n_threads=8)
-    parity.check_final(b.fetch(), ora)
+    b = ref.batch(seqs, lens).run()
+    o.counters(reset=True)
+    ora = o.batch(seqs, lens, n_threads=8)
+    assert o.counters()["n_u8_calls"] > 50                       # the rescue SW really ran
+    dev = b.fetch()
+    parity.check_final(dev, ora)
+    if refdrv.available():
+        r = refdrv.Ref(prefix)
+        parity.check_final(dev, r.batch(seqs, lens, n_threads=8))
+        r.close()
     po = rs.pair_offsets()
     names, offs, clens, alt, l_pac = ref.contigs()
-    parity.check_rfa(b.rfa(po, [True] * 3), rfadrv.oracle_rfa(ora, rs.lens, po, [True] * 3, l_pac, offs))
+    parity.check_rfa(b.rfa(po, [True] * 3), rfadrv.oracle_rfa(ora, lens, po, [True] * 3, l_pac, offs))
     b.free()
+    ref.close()
+
+
+def test_reads_of_256_bases_are_refused(built):
+    from arachne_amd import synth
+    g = synth.make_genome(5, [300_000])
+    tmp = tempfile.mkdtemp(prefix="arx_gpu_len_")
+    prefix = os.path.join(tmp, "g.fa")
+    g.write_fasta(prefix)
+    api.index_build(prefix, prefix)
+    ref = api.load_reference(prefix, 0)
+    with pytest.raises(api.ArachneError, match="255"):
+        ref.batch(np.zeros((2, 256), np.uint8), np.array([256, 256], np.int32))
     ref.close()
 
 

@@ -76,3 +76,23 @@ def unpack_index(npz, dirname, name="golden.fa"):
         if key in npz:
             np.asarray(npz[key], dtype=np.uint8).tofile(prefix + "." + ext)
     return prefix
+
+
+def long_reads(read_len, n_bc=3, ppb=300, mixed=False, contig=1_200_000):
+    """Pairs of the given length (up to MAX_READ_LEN = 255), a quarter of the reads corrupted (15 % or 35 % of their bases) so that the rescue SW has work; mixed: every
+    third pair keeps only its first 150 bases (a batch that holds both element sizes of ksw_align2: KSW_XBYTE below 250 bases, ksw_i16
+    from there on, bwamem_pair.c:150).  Returns genome, ReadSet, sequences (2-D, or flat when mixed) and lengths."""
+    from arachne_amd import synth
+    g = synth.make_genome(500 + read_len, [contig])
+    rs = synth.make_reads(501 + read_len, g, n_bc, ppb, read_len=read_len, sub_rate=0.01)
+    rng = np.random.default_rng(read_len)
+    for i in rng.choice(rs.seqs.shape[0], size=rs.seqs.shape[0] // 4, replace=False):
+        m = rng.random(read_len) < (0.15, 0.35)[i & 1]
+        rs.seqs[i, m] = rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)
+    seqs, lens = rs.seqs, rs.lens
+    if mixed:
+        lens = lens.copy()
+        lens[4::6] = 150
+        lens[5::6] = 150
+        seqs = np.concatenate([rs.seqs[r, :lens[r]] for r in range(len(lens))])
+    return g, rs, seqs, lens
