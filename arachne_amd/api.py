@@ -66,6 +66,7 @@ def _load(path):
     lib.arx_last_error.restype = C.c_char_p
     lib.arx_last_error.argtypes = [vp]
     lib.arx_backend.restype = C.c_char_p
+    lib.arx_index_info.argtypes = [vp, vp]
     lib.arx_contigs.argtypes = [vp] + [vp] * 6
     lib.arx_batch_create.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
     lib.arx_batch_reset.argtypes = [vp, vp, i32, vp, vp]
@@ -520,6 +521,12 @@ class Reference:
         self._check(self.lib.arx_contigs(self.h, C.byref(n), C.byref(names), C.byref(offs), C.byref(lens), C.byref(alt), C.byref(lp)))
         k = n.value
         return ([names[i].decode() for i in range(k)], [offs[i] for i in range(k)], [lens[i] for i in range(k)], [alt[i] for i in range(k)], lp.value)
+
+    def index_info(self) -> dict:
+        """What arx_open built beside the files' content (arx_index_info)."""
+        a = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.arx_index_info(self.h, a.ctypes.data))
+        return dict(symbols=int(a[0]), kmer_k=int(a[1]), kmer_fwd_depth=int(a[2]), sa_rows_per_entry=int(a[3]), text_mode=bool(a[4]), device_bytes=int(a[5]))
 
     def batch(self, seqs, lens) -> Batch:
         return Batch(self, seqs, lens)

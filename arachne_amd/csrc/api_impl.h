@@ -30,6 +30,25 @@ struct KSaDense {
 	ARX_DEV void operator()(int i, int) const { out[i] = sa_lookup(ix, (uint64_t)i * (uint64_t)d); }
 };
 
+// The whole suffix array and its inverse (IndexView::sa40 / isa40), from the rows the files sample: one thread per sampled row walks bwt_sa's LF
+// steps (bwt.c:86-96) to the next sampled row; the rows it passes are those whose own walk would end where it started, so every row and every
+// text position is visited by exactly one thread, which knows both its row and its position.  Row 0 (the empty suffix, sa[0] = -1) stands at
+// position seq_len and gets no entry.
+struct KSaWalk {
+	IndexView ix; uint8_t *sa40, *isa40;
+	ARX_DEV void operator()(int j, int) const
+	{
+		const uint64_t mask = (uint64_t)ix.sa_intv - 1;
+		uint64_t r = (uint64_t)j * (uint64_t)ix.sa_intv, p = j ? ix.sa[j] : ix.seq_len;
+		if (j == 0) p40_store(sa40, 0, 0xffffffffffull);
+		for (;;) {
+			if (r) { p40_store(sa40, r, p); p40_store(isa40, p, r); }
+			r = lf_step(ix, r); --p;
+			if ((r & mask) == 0) break;
+		}
+	}
+};
+
 // k-mer table (dev_fm.h: ktab_*): level d + 1 from level d, one thread per parent; the child of base b is the forward extension by b
 struct KKmerLevel {
 	IndexView ix; const uint64_t *in; uint64_t *out; int d; // in: 4^d entries (null: d == 0, the parents are the four single bases)
@@ -63,6 +82,7 @@ template <class RT> struct Context {
 	std::set<Batch<RT> *> live;
 	std::map<std::string, KernelTimer> tm_done; // timers of batches already freed
 	bool timing = false;
+	uint64_t index_bytes = 0;   // device memory the index holds (arx_index_info)
 
 	void set_error(const std::string &e) { std::lock_guard<std::mutex> g(mu); last_error = e; }
 
@@ -73,6 +93,7 @@ template <class RT> struct Context {
 		if (!e.empty()) return e;
 		e = load_index(prefix, hix);
 		if (!e.empty()) return e;
+		const uint64_t free_at_start = rt.free_bytes();
 		auto up = [&](const void *src, size_t bytes) { void *d = rt.template palloc<uint8_t>(bytes + 64); rt.h2d(d, src, bytes); dev_index.push_back(d); return d; };
 		{ // the Occ blocks go to HBM in the checkpointed layout of dev_fm.h (the files keep BWA's): uploaded as they are, re-packed in place
 			const size_t n_blk = hix.bwt.size() / 16;
@@ -86,7 +107,13 @@ template <class RT> struct Context {
 		}
 		ix.sa = (const uint64_t *)up(hix.sa.data(), hix.sa.size() * 8);
 		std::vector<uint64_t>().swap(hix.sa);
-		ix.pac = (const uint8_t *)up(hix.pac.data(), hix.pac.size());
+		{ // the packed forward strand behind 16 spare bytes: text mode reads the 16 bytes that END at a word of the reverse strand's mirror (dev_fm.h)
+			uint8_t *d = rt.template palloc<uint8_t>(hix.pac.size() + 16 + 64);
+			rt.memset0(d, 16);
+			rt.h2d(d + 16, hix.pac.data(), hix.pac.size());
+			dev_index.push_back(d);
+			ix.pac = d + 16;
+		}
 		std::vector<uint8_t>().swap(hix.pac);
 		ix.ann_off = (const int64_t *)up(hix.ann_off.data(), hix.ann_off.size() * 8);
 		ix.ann_len = (const int32_t *)up(hix.ann_len.data(), hix.ann_len.size() * 4);
@@ -94,20 +121,6 @@ template <class RT> struct Context {
 		ix.primary = hix.primary; ix.seq_len = hix.seq_len;
 		for (int i = 0; i < 5; ++i) ix.L2[i] = hix.L2[i];
 		ix.l_pac = hix.l_pac; ix.n_seqs = (int)hix.names.size(); ix.sa_intv = hix.sa_intv;
-		{ // denser suffix-array sample (ARX_SA_DENSE: rows per sample, a power of two; at least the file's interval switches it off)
-			const char *e = getenv("ARX_SA_DENSE");
-			const int d = e ? atoi(e) : 4; // every 4th row since round 3 (12 GB at GRCh38 size; locate 4.9 -> 2.5 ms per step, arx_open +1.7 s); 8 in round 2
-			const uint64_t n2 = (ix.seq_len + (uint64_t)d) / (uint64_t)d;
-			if (d >= 1 && d < ix.sa_intv && (d & (d - 1)) == 0 && n2 < 0x7fffffffull) {
-				uint64_t *dense = rt.template palloc<uint64_t>((size_t)n2 + 8);
-				KSaDense kd{ix, dense, d};
-				rt.launch_wide("sa_dense", (int)n2, kd);
-				rt.sync();
-				void *old = (void *)ix.sa;
-				for (auto &p : dev_index) if (p == old) { rt.pfree(p); p = dense; }
-				ix.sa = dense; ix.sa_intv = d;
-			}
-		}
 		{ // k-mer table for the third seeding pass (dev_fm.h): K from the genome size -- the largest K with 4^K <= symbols, at most 16 (GRCh38:
 		  // 16, 4.3 G entries = 69 GB of the 288 GB; measured at GRCh38 size: the pass takes 9.7 ms per step without a table, 5.6 at K = 12,
 		  // 4.2 at 14, 3.3 at 16) -- and never more than a third of the device memory that is free; ARX_KMER_K overrides, 0 = no table
@@ -141,7 +154,38 @@ template <class RT> struct Context {
 				ix.ktab = prev; ix.ktab_k = K; ix.klv = lv; ix.klv_k = Kf;
 			}
 		}
+		ix.sa40 = nullptr; ix.isa40 = nullptr;
+		{ // the whole suffix array and its inverse, 5 bytes per entry each (GRCh38: 2 x 31 GB), when they take no more than half of what is free
+		  // after the tables; ARX_TEXT_INDEX=0: never.  With them locating a seed is one load and the first-pass forward extensions compare
+		  // text once one occurrence is left (dev_fm.h: text mode)
+			const char *e = getenv("ARX_TEXT_INDEX");
+			const uint64_t bytes = 5 * (ix.seq_len + 1) + 64;
+			const uint64_t n_sa = (ix.seq_len + (uint64_t)ix.sa_intv) / (uint64_t)ix.sa_intv;
+			if (!(e && atoi(e) == 0) && (ix.sa_intv & (ix.sa_intv - 1)) == 0 && 2 * bytes <= rt.free_bytes() / 2 && n_sa < 0x7fffffffull) {
+				uint8_t *sa40 = rt.template palloc<uint8_t>((size_t)bytes), *isa40 = rt.template palloc<uint8_t>((size_t)bytes);
+				KSaWalk kw{ix, sa40, isa40};
+				rt.launch_wide("sa_walk", (int)n_sa, kw);
+				rt.sync();
+				dev_index.push_back(sa40); dev_index.push_back(isa40);
+				ix.sa40 = sa40; ix.isa40 = isa40;
+			}
+		}
+		if (!ix.sa40) { // denser suffix-array sample (ARX_SA_DENSE: rows per sample, a power of two; at least the file's interval switches it off)
+			const char *e = getenv("ARX_SA_DENSE");
+			const int d = e ? atoi(e) : 4; // every 4th row since round 3 (12 GB at GRCh38 size; locate 4.9 -> 2.5 ms per step, arx_open +1.7 s); 8 in round 2
+			const uint64_t n2 = (ix.seq_len + (uint64_t)d) / (uint64_t)d;
+			if (d >= 1 && d < ix.sa_intv && (d & (d - 1)) == 0 && n2 < 0x7fffffffull) {
+				uint64_t *dense = rt.template palloc<uint64_t>((size_t)n2 + 8);
+				KSaDense kd{ix, dense, d};
+				rt.launch_wide("sa_dense", (int)n2, kd);
+				rt.sync();
+				void *old = (void *)ix.sa;
+				for (auto &p : dev_index) if (p == old) { rt.pfree(p); p = dense; }
+				ix.sa = dense; ix.sa_intv = d;
+			}
+		}
 		for (auto &n : hix.names) name_ptrs.push_back(n.c_str());
+		{ const uint64_t f = rt.free_bytes(); index_bytes = free_at_start > f ? free_at_start - f : 0; }
 		return "";
 	}
 	~Context() { for (void *p : dev_index) rt.pfree(p); }
@@ -223,6 +267,14 @@ template <class RT> struct Batch {
 		return g_open_error.c_str();                                                                                                \
 	}                                                                                                                               \
 	const char *arx_backend(void) { return RT::name(); }                                                                            \
+	int arx_index_info(arx_ctx *h, int64_t *info)                                                                                   \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h;                                                                                                          \
+		info[0] = (int64_t)c->ix.seq_len; info[1] = c->ix.ktab ? c->ix.ktab_k : 0; info[2] = c->ix.klv ? c->ix.klv_k : 0;           \
+		info[3] = c->ix.sa40 ? 1 : c->ix.sa_intv; info[4] = c->ix.isa40 ? 1 : 0; info[5] = (int64_t)c->index_bytes;                 \
+		info[6] = info[7] = 0;                                                                                                      \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
 	int arx_contigs(arx_ctx *h, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens,               \
 	                const int32_t **is_alt, int64_t *l_pac)                                                                         \
 	{                                                                                                                               \

@@ -63,6 +63,11 @@ struct IndexView {
 	// ... and of every prefix of it down to one base, for the forward extensions of the SMEM pass (levels 1 .. klv_k back to back, level d at
 	// entry (4^d - 4) / 3); null / 0: none
 	int32_t klv_k; const uint64_t *klv;
+	// the WHOLE suffix array and its inverse, 40 bits per entry back to back (dev_fm.h: p40_*), built when the index is opened if the memory is
+	// there (GRCh38: 2 x 31 GB): sa40[k] = bwt_sa(k) without the walk; isa40[p] = the row whose suffix starts at text position p.  With both, a
+	// forward extension whose interval has shrunk to ONE occurrence goes on by comparing the read with the reference text (dev_fm.h: FwdLane,
+	// text mode).  null: none (sampled `sa` only)
+	const uint8_t *sa40, *isa40;
 };
 
 struct Biv { uint64_t k, l, s, info; };  // bwtintv_t (bwt.h:59): k = x[0], l = x[1], s = x[2], info = beg<<32|end

@@ -170,8 +170,14 @@ ARX_DEVI Biv ext_finish(const IndexView &ix, const Biv &ik, int is_back, int c, 
 
 ARX_DEVI Biv set_intv(const IndexView &ix, int c) // bwt_set_intv (bwt.h:78)
 {
+	// selects, not ix.L2[c]: a lane-dependent index into the kernel's argument block sends the whole block to scratch memory, and every
+	// field of it the loop reads afterwards comes back through a scratch load instead of a scalar register (k_seed_fwd1: 304 bytes per lane)
+	const uint64_t l0 = ix.L2[0], l1 = ix.L2[1], l2 = ix.L2[2], l3 = ix.L2[3], l4 = ix.L2[4];
 	Biv ik;
-	ik.k = ix.L2[c] + 1; ik.s = ix.L2[c + 1] - ix.L2[c]; ik.l = ix.L2[3 - c] + 1; ik.info = 0;
+	ik.k = (c == 0 ? l0 : c == 1 ? l1 : c == 2 ? l2 : l3) + 1;
+	ik.s = c == 0 ? l1 - l0 : c == 1 ? l2 - l1 : c == 2 ? l3 - l2 : l4 - l3;
+	ik.l = (c == 0 ? l3 : c == 1 ? l2 : c == 2 ? l1 : l0) + 1;
+	ik.info = 0;
 	return ik;
 }
 
@@ -200,6 +206,12 @@ ARX_DEVI Biv klv_load(const IndexView &ix, int d, uint64_t code) // level d (1 .
 	return ktab_unpack(w.a, w.b);
 }
 
+// ---- 40-bit arrays (the whole suffix array and its inverse, IndexView::sa40 / isa40): entry i in bytes [5 i, 5 i + 5), little-endian.
+// Read as the two 32-bit words at the 4-byte boundary below it (the entry ends at most 24 + 40 bits into them); the arrays are padded.
+ARX_DEVI uint64_t p40_decode(uint32_t w0, uint32_t w1, uint64_t i) { return (((uint64_t)w1 << 32 | w0) >> (8 * ((5 * i) & 3))) & 0xffffffffffull; }
+ARX_DEVI uint64_t p40_load(const uint8_t *a, uint64_t i) { const uint32_t *w = (const uint32_t *)(a + ((5 * i) & ~(uint64_t)3)); return p40_decode(w[0], w[1], i); }
+ARX_DEVI void p40_store(uint8_t *a, uint64_t i, uint64_t v) { uint8_t *p = a + 5 * i; p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); p[4] = (uint8_t)(v >> 32); }
+
 // one LF step of bwt_invPsi (bwt.c:53-59)
 ARX_DEVI uint64_t lf_step(const IndexView &ix, uint64_t k)
 {
@@ -215,6 +227,7 @@ ARX_DEVI uint64_t lf_step(const IndexView &ix, uint64_t k)
 // bwt_sa (bwt.c:86-96): LF steps until a sampled row
 ARX_DEVI uint64_t sa_lookup(const IndexView &ix, uint64_t k)
 {
+	if (ix.sa40) return p40_load(ix.sa40, k); // the whole array is resident: no walk
 	uint64_t sa = 0, mask = (uint64_t)ix.sa_intv - 1;
 	while (k & mask) { ++sa; k = lf_step(ix, k); }
 	return sa + ix.sa[k / (uint64_t)ix.sa_intv];
@@ -275,13 +288,142 @@ struct SeedPools { // batch-wide, filled through atomic cursors; an overflow rai
 // would have pushed on the way (depth d whenever the size changes from d to d + 1, bwt.c:308-313) are NOT stored by the lane: n_def says
 // that depths 1 .. n_def are still owed, and the wavefront adds them from the tables when the list is exported to its pool slice
 // (hip_fm_coop.h: persistent_lanes, grant step).
+// TEXT MODE (round 3; needs IndexView::sa40 / isa40).  Once the interval of a first-pass extension holds ONE occurrence (min_intv = 1), every
+// further base either keeps that occurrence or ends the walk: bwt_extend leaves k where it is (the only child is the one that matches) and
+// moves l one LF step along the reverse strand.  The pattern P = q[x0, i) then lies at text position p = SA[k] and nowhere else, so the walk
+// goes on exactly as long as the read equals the text T = forward strand + its reverse complement (bntseq.c:398-419) behind it: compare
+// q[i ...] with T[p + i - x0 ...] until a difference, an ambiguous base, the end of the read or the end of the text, m bases on.  The interval
+// bwt_smem1a would have reached base by base is (k, l', 1) with l' the row of the reverse complement of q[x0, i + m), which lies at the
+// mirror position: l' = ISA[seq_len - (p + i + m - x0)].  Three dependent loads (SA, text, ISA) instead of m round trips to two Occ blocks;
+// the list gets the same single entry the walk would have pushed when it ended (bwt.c:308-316).
+// A lane in text mode asks for what it needs through advance() like an extension: *rc < 0 names the kind, req->k the row / position, and the
+// answer -- 16 bytes from a 4-byte aligned address, aux_addr() -- comes back through consume_aux().
+enum { RC_TAB = -1, RC_SA = -2, RC_TEXT = -3, RC_ISA = -4 };
+enum { FL_NORMAL = 0, FL_SA = 1, FL_TEXT = 2, FL_ISA = 3 };
+
+// first 32-bit word of the 16-byte chunk of the packed forward strand that holds text position t and what follows it in T: on the forward
+// strand the words from t's own on, on the reverse strand (read downwards) the word of the mirrored position and the three below it
+ARX_DEVI int64_t text_chunk_word(const IndexView &ix, uint64_t t)
+{
+	if ((int64_t)t < ix.l_pac) return (int64_t)(t >> 4);
+	return (((ix.l_pac << 1) - 1 - (int64_t)t) >> 4) - 3; // (down to -3: the packed strand is resident behind 16 spare bytes, api_impl.h)
+}
+ARX_DEVI const uint32_t *aux_addr(const IndexView &ix, int rc, uint64_t x)
+{
+	if (rc == RC_SA) return (const uint32_t *)(ix.sa40 + ((5 * x) & ~(uint64_t)3));
+	if (rc == RC_ISA) return (const uint32_t *)(ix.isa40 + ((5 * x) & ~(uint64_t)3));
+	if (rc == RC_TEXT) return (const uint32_t *)ix.pac + text_chunk_word(ix, x);
+	return (const uint32_t *)(ix.klv + 2 * (((((uint64_t)1 << (2 * ix.klv_k)) - 4) / 3) + x)); // RC_TAB: the klv_k-mer with code x
+}
+
+// q[i ...] against T[t ...] within the 16-byte chunk w0..w3 (the words at text_chunk_word(t)): the number of equal bases; *more: the chunk ran
+// out first, and both the read and the text go on.  Base by base (any read layout; the host test double and the one-thread kernels):
+template <class Q> ARX_DEVI int text_match_chunk(const IndexView &ix, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint64_t t, const Q &q, int i, int len, bool *more)
+{
+	const uint32_t w[4] = {w0, w1, w2, w3};
+	const uint8_t *wb = (const uint8_t *)w;
+	const int64_t base0 = text_chunk_word(ix, t) * 16;
+	int m = 0, avail;
+	if ((int64_t)t < ix.l_pac) {
+		const int64_t a0 = (int64_t)t - base0;
+		avail = (int)(64 - a0 < ix.l_pac - (int64_t)t ? 64 - a0 : ix.l_pac - (int64_t)t);
+		for (; m < avail; ++m) {
+			const int rel = (int)a0 + m;
+			if (i + m >= len || q.at(i + m) != ((wb[rel >> 2] >> ((~rel & 3) << 1)) & 3)) break;
+		}
+	} else {
+		const int64_t u = (ix.l_pac << 1) - 1 - (int64_t)t;
+		avail = (int)(u - base0 + 1 < u + 1 ? u - base0 + 1 : u + 1);
+		for (; m < avail; ++m) {
+			const int rel = (int)(u - base0) - m;
+			if (i + m >= len || q.at(i + m) != 3 - ((wb[rel >> 2] >> ((~rel & 3) << 1)) & 3)) break;
+		}
+	}
+	*more = m == avail && i + m < len && t + (uint64_t)m < ix.seq_len;
+	return m;
+}
+
+// The same for a read staged as a row of 4-bit codes (QNibbles: the wavefront kernels), 64 bases at a time on words: both sides become streams
+// of 2-bit codes, first base in the lowest bits -- the text by undoing the packed strand's byte order (forward strand: MSB-first within a
+// byte, bytes ascending; the reverse strand is read downwards and complemented, which is the byte-swapped word inverted), the read by
+// squeezing the low two bits out of every nibble, with bit 2 of a nibble (codes above 3) kept as a difference of its own.
+ARX_DEVI uint32_t text_rev32(uint32_t x)
+{
+#if defined(__clang__)
+	return __builtin_bitreverse32(x);
+#else
+	x = (x >> 16) | (x << 16); x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8); x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+	x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2); return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+#endif
+}
+ARX_DEVI uint32_t text_fwd_word(uint32_t r) { const uint32_t x = text_rev32(__builtin_bswap32(r)); return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); }
+ARX_DEVI uint32_t text_rev_word(uint32_t r) { return ~__builtin_bswap32(r); }
+ARX_DEVI uint32_t nib_squeeze(uint32_t n) { uint32_t y = n & 0x33333333u; y = (y | y >> 2) & 0x0f0f0f0fu; y = (y | y >> 4) & 0x00ff00ffu; return (y | y >> 8) & 0xffffu; }
+ARX_DEVI uint32_t text_funnel(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); } // sh in [0, 31]
+ARX_DEVI int text_match_chunk(const IndexView &ix, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint64_t t, const QNibbles &q, int i, int len, bool *more)
+{
+	uint32_t s0, s1, s2, s3;
+	int sh, avail;
+	if ((int64_t)t < ix.l_pac) {
+		const int a0 = (int)(t & 15);
+		s0 = text_fwd_word(w0); s1 = text_fwd_word(w1); s2 = text_fwd_word(w2); s3 = text_fwd_word(w3);
+		sh = 2 * a0;
+		avail = (int)(64 - a0 < ix.l_pac - (int64_t)t ? 64 - a0 : ix.l_pac - (int64_t)t);
+	} else {
+		const int64_t u = (ix.l_pac << 1) - 1 - (int64_t)t;
+		const int bu = (int)(u & 15);
+		s0 = text_rev_word(w3); s1 = text_rev_word(w2); s2 = text_rev_word(w1); s3 = text_rev_word(w0);
+		sh = 2 * (15 - bu);
+		avail = (int)(bu + 49 < u + 1 ? bu + 49 : u + 1);
+	}
+	const uint32_t z0 = text_funnel(s1, s0, sh), z1 = text_funnel(s2, s1, sh), z2 = text_funnel(s3, s2, sh), z3 = s3 >> sh;
+	const uint32_t *row = (const uint32_t *)q.p + (i >> 3);
+	const int rs = 2 * (i & 7);
+	uint32_t r[5], f[5];
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+	for (int j = 0; j < 5; ++j) {
+		const uint32_t a = row[2 * j], b = j < 4 ? row[2 * j + 1] : 0;
+		r[j] = nib_squeeze(a) | nib_squeeze(b) << 16;
+		f[j] = nib_squeeze(a >> 2) | nib_squeeze(b >> 2) << 16;
+	}
+	const uint32_t d0 = (z0 ^ text_funnel(r[1], r[0], rs)) | text_funnel(f[1], f[0], rs), d1 = (z1 ^ text_funnel(r[2], r[1], rs)) | text_funnel(f[2], f[1], rs);
+	const uint32_t d2 = (z2 ^ text_funnel(r[3], r[2], rs)) | text_funnel(f[3], f[2], rs), d3 = (z3 ^ text_funnel(r[4], r[3], rs)) | text_funnel(f[4], f[3], rs);
+	int m = d0 ? __builtin_ctz(d0) >> 1 : d1 ? 16 + (__builtin_ctz(d1) >> 1) : d2 ? 32 + (__builtin_ctz(d2) >> 1) : d3 ? 48 + (__builtin_ctz(d3) >> 1) : 64;
+	if (m > avail) m = avail;
+	if (m > len - i) m = len - i;
+	*more = m == avail && i + m < len && t + (uint64_t)m < ix.seq_len;
+	return m;
+}
+
 template <class Q> struct FwdLane {
-	Q q; Biv *list; int len, i, min_intv, n, last_end; bool finished; Biv ik;
+	Q q; Biv *list; int len, i, min_intv, n; bool finished; Biv ik;
 	int n_def, x0; uint32_t code; // owed list prefix (0: none), the start, the code of its first klv_k bases
+	int mode; bool text_ok; uint64_t tpos; // text mode: FL_*; what the next request is about: the row k (FL_SA), the text position beside q[i] (FL_TEXT), the position whose row is asked for (FL_ISA)
 	ARX_DEVI void start(const IndexView &ix, int len_, const Q &q_, int x, int min_intv_, Biv *list_)
 	{
-		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false; last_end = 0; n_def = 0; x0 = x; code = 0;
+		q = q_; list = list_; len = len_; min_intv = min_intv_; n = 0; finished = false; n_def = 0; x0 = x; code = 0;
+		mode = FL_NORMAL; text_ok = ix.sa40 && ix.isa40 && min_intv_ == 1; tpos = 0;
 		ik = set_intv(ix, q.at(x)); ik.info = x + 1; i = x + 1;
+	}
+	ARX_DEVI void enter_text() { if (text_ok && ik.s == 1 && i < len && q.at(i) <= 3) { mode = FL_SA; tpos = ik.k; } } // one occurrence left and a base to try
+	ARX_DEVI void finish_text() { list[n++] = ik; finished = true; mode = FL_NORMAL; }
+	ARX_DEVI void consume_aux(const IndexView &ix, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) // the 16 bytes at aux_addr() of the last request
+	{
+		if (mode == FL_SA) {
+			const uint64_t t = p40_decode(w0, w1, ik.k) + (uint64_t)(i - x0);
+			if (t >= ix.seq_len) { finish_text(); return; } // the pattern ends the text: no base extends it
+			tpos = t; mode = FL_TEXT;
+		} else if (mode == FL_TEXT) {
+			bool more;
+			const int m = text_match_chunk(ix, w0, w1, w2, w3, tpos, q, i, len, &more);
+			i += m; tpos += (uint64_t)m; ik.info = (uint64_t)i;
+			if (!more) { tpos = ix.seq_len - tpos; mode = FL_ISA; }
+		} else {
+			ik.l = p40_decode(w0, w1, tpos);
+			finish_text();
+		}
 	}
 	// start(), and true if the interval of the first klv_k bases may be asked for (*code_out: its table index); the caller then hands it to take_jump()
 	ARX_DEVI bool start_jump(const IndexView &ix, int len_, const Q &q_, int x, int min_intv_, Biv *list_, uint64_t *code_out)
@@ -299,23 +441,26 @@ template <class Q> struct FwdLane {
 		if (t.s < (uint64_t)min_intv) return; // the walk ends inside the first K bases: base by base from the start, as set up by start()
 		const int K = ix.klv_k;
 		ik = t; ik.info = x0 + K; i = x0 + K; n_def = K - 1;
+		enter_text();
 	}
 	ARX_DEVI bool advance(Biv *req, int *rc)
 	{
 		if (finished) return false;
-		if (i >= len || q.at(i) > 3) { list[n++] = ik; last_end = (int)ik.info; finished = true; return false; }
+		if (mode != FL_NORMAL) { req->k = tpos; *rc = -1 - mode; return true; } // (tpos holds the operand of every kind: a select between two members here would send the lane's state to scratch memory)
+		if (i >= len || q.at(i) > 3) { list[n++] = ik; finished = true; return false; }
 		*req = ik; *rc = 3 - q.at(i);
 		return true;
 	}
 	ARX_DEVI void consume(const Biv &ok)
 	{
 		if (ok.s != ik.s) {
-			list[n++] = ik; last_end = (int)ik.info;
+			list[n++] = ik;
 			if (ok.s < (uint64_t)min_intv) { finished = true; return; }
 		}
 		ik = ok; ik.info = i + 1; ++i;
+		enter_text();
 	}
-	ARX_DEVI int ret() const { return last_end; } // (int)list[n - 1].info, kept in a register: where the longest match ends = the next start of the first pass
+	ARX_DEVI int ret() const { return (int)ik.info; } // once finished: where the longest match ends = the next start of the first pass (every way the walk ends pushes ik last, bwt.c:308-316)
 };
 
 // list[0..n) of a finished forward extension becomes a task: the pool slice gets it longest first (bwt.c:322)
@@ -341,14 +486,51 @@ ARX_DEVI void seed_export_into(const SeedPools &P, int t, const Biv *list, int n
 // backward half of bwt_smem1a (bwt.c:323-349) for one task.  Most rows of a sweep hold a single interval (a unique match
 // narrows to one size quickly): entry 0 of both lists therefore lives in registers only (prev0 / curr0) and such rows touch
 // no list memory at all; entries 1.. go through the task's pool slice.
+// Text mode for the backward sweep (see FwdLane): a row that has shrunk to ONE interval holding ONE occurrence (min_intv = 1) goes on base by
+// base until the read differs from the text before the pattern, an ambiguous base or either start is reached -- and then that interval is
+// the SMEM, if it is not contained in the last one found (bwt.c:326-345).  Backward extension leaves l where it is and moves k: the pattern
+// q[i + 1 ...) lies at p = SA[k], after m more bases it is q[i + 1 - m ...) at p - m, whose row is ISA[p - m].
+// ent: the interval; i: the next read index to try (-1: before the read).  Returns the new number of SMEMs in mem[].
+template <class Q> ARX_DEVI int bwd_text_tail(const IndexView &ix, const Q &q, const Biv &ent, int i, int nm, int mem_last_start, Biv *mem)
+{
+	const uint64_t p = p40_load(ix.sa40, ent.k);
+	int m = 0;
+	while (i - m >= 0 && (uint64_t)m < p) {
+		const int b = q.at(i - m);
+		if (b > 3 || b != ref_base(ix, (int64_t)(p - 1 - (uint64_t)m))) break;
+		++m;
+	}
+	const int start = i - m + 1;
+	if (nm == 0 || start < mem_last_start) {
+		Biv x = ent;
+		if (m) x.k = p40_load(ix.isa40, p - (uint64_t)m);
+		x.info |= (uint64_t)start << 32;
+		mem[nm++] = x;
+	}
+	return nm;
+}
+
+// what k_seed_bwd_g leaves of such a sweep (hip_fm_coop.h: the interval in the task's second list, row / nm / mls in the task, flag 2): one thread each
+struct KSeedBwdTail {
+	IndexView ix; const uint8_t *bases; const int32_t *base_off; Biv *pool; SeedTask *tasks; int t0; const uint8_t *flag;
+	ARX_DEV void operator()(int item, int) const
+	{
+		if (flag[item] != 2) return;
+		SeedTask &k = tasks[t0 + item];
+		k.nm = bwd_text_tail(ix, QBytes{bases + base_off[k.read]}, pool[k.off + k.n], k.row, k.nm, k.mls, pool + k.off + 2 * k.n);
+	}
+};
+
 template <class Q> struct BwdLane {
 	Q q; Biv *prev, *curr, *mem; int min_intv, i, j, c, n_prev, n_curr, nm, mem_last_start; bool finished, in_row;
 	uint64_t curr_last_s; // curr[n_curr - 1].s and the start of mem[nm - 1] are kept in registers: both are looked at after every extension
 	Biv prev0, curr0;
 	int n_done, handed; // extensions so far; 1: the sweep stopped at a row boundary for somebody else to go on with (state in *this)
+	const IndexView *tix; // text mode (bwd_text_tail) for the one-thread form: null = off
+	ARX_DEVI void use_text(const IndexView &ix) { tix = ix.sa40 && ix.isa40 && min_intv == 1 ? &ix : nullptr; } // after start()
 	ARX_DEVI void start(const Q &q_, const SeedTask &t, Biv *pool)
 	{
-		n_done = 0; handed = 0;
+		n_done = 0; handed = 0; tix = nullptr;
 		q = q_; prev = pool + t.off; curr = prev + t.n; mem = curr + t.n; min_intv = t.min_intv;
 		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
 		prev0 = prev[0]; curr0 = Biv();
@@ -358,7 +540,7 @@ template <class Q> struct BwdLane {
 	ARX_DEVI bool has_next_entry() const { return !finished && in_row && j + 1 < n_prev; }
 	ARX_DEVI void start_with(const Q &q_, const SeedTask &t, Biv *pool, const Biv &first) // start() with prev[0] already in hand
 	{
-		n_done = 0; handed = 0;
+		n_done = 0; handed = 0; tix = nullptr;
 		q = q_; prev = pool + t.off; curr = prev + t.n; mem = curr + t.n; min_intv = t.min_intv;
 		n_prev = t.n; i = t.x - 1; j = 0; c = 0; n_curr = 0; nm = 0; mem_last_start = 0; curr_last_s = 0; finished = false; in_row = false;
 		prev0 = first; curr0 = Biv();
@@ -372,6 +554,7 @@ template <class Q> struct BwdLane {
 		while (!finished) {
 			if (!in_row) { // backward extension by query position i (-1 = before the read)
 				if (i < -1) { finished = true; break; }
+				if (tix && n_prev == 1 && prev0.s == 1) { nm = bwd_text_tail(*tix, q, prev0, i, nm, mem_last_start, mem); finished = true; break; }
 				if (budget > 0 && n_done >= budget) { prev[0] = prev0; handed = 1; finished = true; break; }
 				c = i < 0 ? -1 : (q.at(i) < 4 ? q.at(i) : -1);
 				n_curr = 0; j = 0;

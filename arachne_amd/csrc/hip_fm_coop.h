@@ -62,6 +62,9 @@ inline int seed_row_bytes(int max_len) { int w = ((max_len + 1) / 2 + 3) / 4; if
 #ifndef ARX_SEED_WPE
 #define ARX_SEED_WPE 4 // waves per SIMD the seeding kernels are compiled for (register budget 512 / WPE)
 #endif
+#ifndef ARX_SEED_FWD_WPE
+#define ARX_SEED_FWD_WPE 4 // ... and the two forward kernels (5 and 6 were measured: the spills cost more than the wavefronts bring, profiles/r03/README.md)
+#endif
 
 // The reads of a batch as the seeding kernels want them: 4-bit codes, two per byte (low nibble first), one fixed-stride row of `row`
 // bytes per read.  Packed once per batch (k_pack_reads); a lane that takes an item then copies ITS row into its LDS row with
@@ -203,7 +206,12 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 		last = t;
 		if (awaiting) { awaiting = false; shelve(); } // the parked second list moves up
 	}
-	__device__ void consume(const Biv &, const Biv &ok) { if (want_tab) { want_tab = false; ln.take_jump(A.ix, ok); } else ln.consume(ok); }
+	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
+	__device__ void consume_aux(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) // the answer to a request with *rc < 0: the k-mer's table entry, or what text mode asked for (dev_fm.h)
+	{
+		if (want_tab) { want_tab = false; ln.take_jump(A.ix, ktab_unpack((uint64_t)w1 << 32 | w0, (uint64_t)w3 << 32 | w2)); }
+		else ln.consume_aux(A.ix, w0, w1, w2, w3);
+	}
 	__device__ bool done() const { return over && pend_n == 0; }
 	__device__ void finish() { A.first1[r] = head; }
 };
@@ -242,6 +250,7 @@ struct FwdProg2 { // re-seeding: the forward extension of one task
 		A.P.tasks[t].off = off; A.P.tasks[t].n = ln.n; // the list itself was copied to pool + off by the wavefront, persistent_lanes()
 	}
 	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
+	__device__ void consume_aux(uint32_t, uint32_t, uint32_t, uint32_t) {}
 	__device__ bool done() const { return over; }
 	__device__ void finish() {}
 };
@@ -273,6 +282,7 @@ struct BwdProg { // the backward sweep of one task
 	__device__ int export_x() const { return 0; }
 	__device__ void granted(int, int, int) {}
 	__device__ void consume(const Biv &req, const Biv &ok) { ln.consume(req, ok); }
+	__device__ void consume_aux(uint32_t, uint32_t, uint32_t, uint32_t) {}
 	__device__ bool done() const { return ln.finished; }
 	__device__ void finish()
 	{
@@ -442,23 +452,25 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
 		}
-		if (Prog::NEW_TASK && A.ix.klv) { // first pass with k-mer tables: a lane that starts an extension asks for ONE table entry (rc < 0) where the
-			// others ask for an extension; the table load of every lane (entry 0 for those that do not want one: a cached line) is issued ahead of
-			// the Occ loads, so that one wait covers both kinds
-			const bool is_tab = have_req && rc < 0;
-			const Biv tab = klv_load(A.ix, A.ix.klv_k, is_tab ? req.k : 0);
-			if (have_req) { Biv ok = tab; if (!is_tab) ok = extend1(A.ix, req, rb, rc); prog.consume(req, ok); have_req = false; }
+		if (Prog::NEW_TASK && (A.ix.klv || A.ix.isa40)) { // first pass with k-mer tables and / or text mode: a lane may ask for 16 bytes from
+			// somewhere (rc < 0: a table entry, a suffix-array entry, reference text; dev_fm.h aux_addr) where the others ask for an extension; that
+			// load is issued for every lane (the first Occ block for those that want none: a cached line) ahead of the Occ loads, so that one
+			// wait covers both kinds
+			const bool is_aux = have_req && rc < 0;
+			const uint32_t *ap = is_aux ? aux_addr(A.ix, rc, req.k) : A.ix.bwt;
+			const uint32_t x0 = ap[0], x1 = ap[1], x2 = ap[2], x3 = ap[3];
+			if (have_req) { if (is_aux) prog.consume_aux(x0, x1, x2, x3); else prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 		} else if (have_req) { prog.consume(req, extend1(A.ix, req, rb, rc)); have_req = false; }
 	}
 	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 2, n_slow); atomicAdd(A.dbg + 3, 1ull); }
 }
 
-static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_fwd1(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+static __global__ void __launch_bounds__(64, ARX_SEED_FWD_WPE) k_seed_fwd1(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
 {
 	extern __shared__ uint8_t q_lds[]; // 64 rows of A.row bytes
 	persistent_lanes<FwdProg1, false>(A, n, counter, batch, chunk, q_lds);
 }
-static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_fwd2(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
+static __global__ void __launch_bounds__(64, ARX_SEED_FWD_WPE) k_seed_fwd2(SeedKArgs A, int n, int32_t *counter, int batch, int chunk)
 {
 	extern __shared__ uint8_t q_lds[]; // 64 rows of A.row bytes
 	persistent_lanes<FwdProg2, true>(A, n, counter, batch, chunk, q_lds);
@@ -586,6 +598,13 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 	for (;;) {
 		// A. running groups: the base to extend by, or the sweep is over
 		bool ext = false;
+		// text mode (dev_fm.h bwd_text_tail): a row that is ONE interval with ONE occurrence is not walked here -- three dependent loads and a
+		// comparison with the reference text finish it, one thread per such sweep after this kernel (KSeedBwdTail); the group is free for the next task
+		const bool to_tail = A.ix.isa40 && stage == 3 && n_prev == 1 && k.min_intv == 1 && i >= -1 && (__ballot(gl == 0 && ent.s == 1) & gmask);
+		if (to_tail) {
+			if (gl == 0) { SeedTask &kt = A.P.tasks[t]; A.P.pool[k.off + k.n] = ent; kt.row = i; kt.nm = nm; kt.mls = mls; heavy_flag[t - A.t0] = 2; }
+			stage = 0;
+		}
 		if (stage == 3) {
 			bool over = i < -1;
 			if (!over) {
@@ -718,7 +737,7 @@ static __global__ void __launch_bounds__(256) k_bin_tasks(const SeedTask *tasks,
 static __global__ void __launch_bounds__(256) k_collect_heavy(const uint8_t *flag, int n, int t0, int32_t *heavy, int32_t *n_heavy)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && flag[i]) heavy[atomicAdd(n_heavy, 1)] = t0 + i;
+	if (i < n && flag[i] == 1) heavy[atomicAdd(n_heavy, 1)] = t0 + i; // (2: text mode's tails, KSeedBwdTail)
 }
 
 struct StratArgs { IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; Biv *strat; int32_t *n_strat; int row; const uint32_t *qn; };

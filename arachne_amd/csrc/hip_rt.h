@@ -173,6 +173,7 @@ struct HipRT {
 	int max_seed_slots() const { return n_cu * seed_bpc * 64; }
 	// the row-parallel backward kernel needs 94 VGPRs: five wavefronts per SIMD fit, not only the four its launch bound asks for, so its grid is
 	// 20 workgroups per CU (4.81 -> 4.62 ms alone; 24 and more lose again, and a build that forces six per SIMD spills: 7.2 ms)
+	bool text_bwd = !(getenv("ARX_TEXT_BWD") && atoi(getenv("ARX_TEXT_BWD")) == 0);
 	int seed_bwd_bpc = getenv("ARX_SEED_BWD_BPC") ? atoi(getenv("ARX_SEED_BWD_BPC")) : 20;
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
 	void set_seed_read_len(int max_len) { seed_row = seed_row_bytes(max_len); }
@@ -395,6 +396,7 @@ struct HipRT {
 		int32_t *heavy = alloc<int32_t>((size_t)n + 2);
 		memset0(heavy + n, 4);
 		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row, seed_qn, 0, seed_dbg()};
+		if (!text_bwd) A.ix.isa40 = nullptr; // ARX_TEXT_BWD=0: every sweep walked to its end (k_seed_bwd_g hands nothing to KSeedBwdTail)
 		if (seed_bwd2 == 2 && seed_row <= 132) { // row-parallel sweeps (k_seed_bwd_g<GL>): one task per 16/32/64-lane group, lists in registers
 			uint8_t *flag = alloc<uint8_t>((size_t)n + 8);
 			int32_t *bins = alloc<int32_t>(3 * (size_t)n + 8), *cnt = alloc<int32_t>(8); // cnt[0..2]: bin sizes, cnt[4..6]: the three launches' item counters
@@ -415,6 +417,10 @@ struct HipRT {
 				Scope sc(*this, "seed_bwd_wave", n);
 				hipLaunchKernelGGL(k_collect_heavy, dim3((n + 255) / 256), dim3(256), 0, stream, flag, n, f.t0, heavy, heavy + n);
 				hipLaunchKernelGGL(k_seed_bwd_wave, dim3(n_cu * 16), dim3(64), 0, stream, A);
+				if (A.ix.isa40) { // the sweeps k_seed_bwd_g left at a row of one interval with one occurrence (text mode)
+					KSeedBwdTail kt{f.ix, f.bases, f.base_off, f.P.pool, f.P.tasks, f.t0, flag};
+					hipLaunchKernelGGL(k_items<KSeedBwdTail>, dim3((n + 63) / 64), dim3(64), 0, stream, kt, n);
+				}
 				ARX_HIP_CHECK(hipGetLastError());
 			}
 			return;
@@ -462,6 +468,7 @@ struct HipRT {
 	{
 		if (n <= 0) return;
 		if (sw_simple) { launch(nm, n, f); return; }
+		if (f.ix.sa40) { launch_wide(nm, n, f); return; } // the whole suffix array is resident: one load per occurrence, no walk to balance
 		memset0(counter, 4);
 		Scope sc(*this, nm, n);
 		int blocks = (n + 255) / 256; if (blocks > n_cu * 8) blocks = n_cu * 8;

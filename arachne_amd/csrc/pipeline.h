@@ -48,7 +48,11 @@ struct KSeedFwd1 { // first pass, forward halves: the starts of a read chain thr
 				ln.start(ix, len, q, x, 1, list);
 				Biv req = Biv();
 				int rc = 0;
-				while (ln.advance(&req, &rc)) ln.consume(extend1(ix, req, 0, rc));
+				while (ln.advance(&req, &rc)) {
+					if (rc >= 0) { ln.consume(extend1(ix, req, 0, rc)); continue; }
+					const uint32_t *a = aux_addr(ix, rc, req.k); // text mode (dev_fm.h)
+					ln.consume_aux(ix, a[0], a[1], a[2], a[3]);
+				}
 				const int t = seed_export(P, r, x, 1, list, ln.n);
 				if (t < 0) break;
 				if (last >= 0) P.tasks[last].next = t; else head = t;
@@ -68,6 +72,7 @@ struct KSeedBwd { // the backward sweep of task t0 + item
 		if (t.n == 0) return;
 		BwdLane<QBytes> ln;
 		ln.start(QBytes{bases + base_off[t.read]}, t, P.pool);
+		ln.use_text(ix);
 		Biv req = Biv();
 		int rc = 0;
 		int n_ext = 0;
@@ -588,6 +593,19 @@ public:
 			rt.run_seed_fwd1("seed_fwd", Rg, kf, w.counter);
 			rt.d2h(cur, P.cursors, 8);
 			const int n1 = cur[1] < P.task_cap ? cur[1] : P.task_cap;
+			if (getenv("ARX_SEED_DUMP")) { // diagnostics: the first-pass tasks of the first reads and their forward lists
+				for (int r = 0; r < 3 && r < Rg; ++r) {
+					int32_t t = 0;
+					rt.d2h(&t, first1 + g0 + r, 4);
+					while (t >= 0 && t < n1) {
+						SeedTask k; rt.d2h(&k, P.tasks + t, sizeof k);
+						fprintf(stderr, "[arx seed dump] read %d task %d x %d n %d:", r, t, k.x, k.n);
+						for (int e = 0; e < k.n && e < 24; ++e) { Biv v; rt.d2h(&v, P.pool + k.off + e, sizeof v); fprintf(stderr, " (s %llu end %d)", (unsigned long long)v.s, (int)(uint32_t)v.info); }
+						fprintf(stderr, "\n");
+						t = k.next;
+					}
+				}
+			}
 			KSeedBwd kb{ix, b.bases, b.base_off, b.lens, P, 0};
 			rt.run_seed_bwd("seed_bwd", n1, kb, w.counter);
 			KSeedGather1 kg1{b.bases, b.base_off, P, first1, w.intv, w.n_intv, first2, g0};

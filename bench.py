@@ -222,9 +222,10 @@ def algorithmic_bytes(prefix, rs, n_sample):
     per_read_strat = 64.0 * (c["ext3_same_block"] + 2 * c["ext3_two_block"]) / reads + L / 4
     per_read_locate = (64.0 * c["sa_lf_steps"] + 8.0 * c["sa_lookups"]) / reads       # the reference's walk: to a sample every 32nd row
     per_read_locate8 = (64.0 * c["sa_lf_steps8"] + 8.0 * c["sa_lookups"]) / reads     # the same lookups walked to a sample every 8th row
+    per_read_locate1 = 8.0 * c["sa_lookups"] / reads                                       # ... with the whole array resident: the entries themselves
     per_read_locate4 = (64.0 * c.get("sa_lf_steps4", c["sa_lf_steps8"] * 3.0 / 7.0) + 8.0 * c["sa_lookups"]) / reads   # ... every 4th row (the product's default since round 3)
     o.close()
-    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, locate8=per_read_locate8, locate4=per_read_locate4,
+    return dict(seed=per_read_seed, fwd=per_read_fwd, bwd=per_read_bwd, strat=per_read_strat, locate=per_read_locate, locate8=per_read_locate8, locate4=per_read_locate4, locate1=per_read_locate1,
                 counters={k: v / reads for k, v in c.items() if k != "n_reads"})
 
 
@@ -323,6 +324,7 @@ def main():
         ref = api.load_reference(prefix, device=local_rank)
         assert ref.backend == "hip:gfx950", ref.backend
     setup["arx_open_s"] = round(time.time() - t, 2)
+    index_info = ref.index_info()           # what arx_open built: k-mer tables, the whole suffix array and its inverse (text mode) or the sample
     index_bytes = {ext: os.path.getsize(prefix + "." + ext) for ext in ("bwt", "sa", "pac")}
     # whole barcodes per device batch; reads go to HBM before the clock starts
     po = rs.pair_offsets()
@@ -527,6 +529,7 @@ def main():
         # steps, the boundary pass (one sizing step + its steps), the "alone" pass
         out["whole_path_passes"] = len(sets) + args.warmup + args.steps + (1 + args.boundary_steps if (args.boundary_steps > 0 and args.stagger) else 0) + 1
         out["setup_s"] = setup
+        out["index"] = index_info
         if boundary:
             out_bytes = sum(int(c["n_regs"]) * (88 + 48) + int(c["n_cigar"]) * 4 + int(c["n_reads"]) * 8 for c in counts) + sum(b._n_cands for b in batches) * 96
             if scatter_info:
@@ -610,10 +613,11 @@ def main():
                 avg_ms = kl["ms"] / kl["calls"]
                 # the bytes of the walk the kernel does: the same lookups, each walked to the first row that is a multiple of the
                 # device's sample interval (counted by the restatement for 8; the reference's own walk to every 32nd row beside it)
-                dense = int(os.environ.get("ARX_SA_DENSE", "4"))
-                per_read = ab["locate4"] if dense == 4 else ab["locate8"] if dense == 8 else ab["locate"]
+                dense = index_info["sa_rows_per_entry"]
+                per_read = ab["locate1"] if dense == 1 else ab["locate4"] if dense == 4 else ab["locate8"] if dense == 8 else ab["locate"]
                 ach = per_read * reads_per_launch / max(avg_ms * 1e-3, 1e-12) / 1e9
-                out["roofline_locate"] = dict(kernel="locate (k_locate_dyn: bwt_sa LF walk to the suffix-array sample every %d-th row)" % dense, bound=bound,
+                out["roofline_locate"] = dict(kernel=("locate (KLocate: one entry of the resident suffix array per occurrence, no walk)" if dense == 1 else
+                                                      "locate (k_locate_dyn: bwt_sa LF walk to the suffix-array sample every %d-th row)" % dense), bound=bound,
                                               achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, algorithmic_bytes_per_read=per_read,
                                               reference_walk_bytes_per_read=ab["locate"], avg_launch_ms=avg_ms)
             out["work_per_read"] = ab["counters"]

@@ -58,13 +58,18 @@ typedef struct { int64_t rbeg; int32_t qbeg, len; } arx_seed;                   
 int arx_index_build(const char *fasta, const char *prefix, char *msg, int32_t msg_cap);
 
 /* Loads <prefix>.{bwt,sa,pac,ann,amb,alt} (files written by `bwa index`) into HBM of `device`; derives there, once, what the kernels use
- * beside the files' content: the Occ blocks re-packed for one popcount per count, the suffix-array sample every 4th row (ARX_SA_DENSE), the
- * k-mer tables of the seeding passes (ARX_KMER_K / ARX_KMER_FWD: up to 69 GB + 5.7 GB at GRCh38 size, never more than a third of the free
- * memory).  ~4 s for GRCh38. */
+ * beside the files' content: the Occ blocks re-packed for one popcount per count; the k-mer tables of the seeding passes (ARX_KMER_K /
+ * ARX_KMER_FWD: up to 69 GB + 5.7 GB at GRCh38 size, never more than a third of the free memory); the WHOLE suffix array and its inverse,
+ * 40 bits per entry (2 x 31 GB at GRCh38 size, when they take no more than half of what is free after the tables; ARX_TEXT_INDEX=0: never),
+ * or else the suffix-array sample every 4th row (ARX_SA_DENSE).  arx_index_info says what was built.  ~5 s for GRCh38. */
 int arx_open(const char *prefix, int device, arx_ctx **out);
 void arx_close(arx_ctx *ctx); /* also frees the context's batches that are still alive: their handles are invalid afterwards */
 const char *arx_last_error(arx_ctx *ctx);      /* ctx may be NULL after a failed arx_open */
 const char *arx_backend(void);                 /* "hip:gfx950" for the product library */
+/* info[0] symbols of the index (2 x l_pac); [1] K of the k-mer table of the third seeding pass (0: none); [2] deepest per-depth table of the
+ * forward extensions (0: none); [3] rows per resident suffix-array entry (1: the whole array); [4] 1 if the inverse suffix array is resident
+ * (text mode of the seeding passes); [5] bytes of device memory the index holds; [6], [7] reserved (0) */
+int arx_index_info(arx_ctx *ctx, int64_t *info /* 8 */);
 
 int arx_contigs(arx_ctx *ctx, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens,
                 const int32_t **is_alt, int64_t *l_pac);

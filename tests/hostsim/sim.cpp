@@ -221,5 +221,51 @@ extern "C" long arx_test_dedup_insert(unsigned seed, int iters, long *n_fast, lo
 	return cases;
 }
 
+// test entry: text mode's word-parallel comparison (dev_fm.h text_match_chunk on a row of 4-bit codes, what the wavefront kernels run) against
+// the base-by-base form on random packed strands and reads: matching stretches of every length, both strands, chunks that end at the
+// strand boundary and at either end of the text, ambiguous bases, reads that end inside the chunk.  Returns the cases compared (< 0: first mismatch).
+extern "C" long arx_test_text_match(unsigned seed, int iters)
+{
+	using namespace arx;
+	uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1);
+	auto rnd = [&](int m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (int)(x % (uint64_t)m); };
+	long cases = 0;
+	for (int it = 0; it < iters; ++it) {
+		const int64_t l_pac = 40 + rnd(it % 5 == 0 ? 60 : 700);
+		std::vector<uint8_t> store((size_t)(l_pac / 4 + 1 + 16 + 64), 0);
+		uint8_t *pac = store.data() + 16;
+		for (int64_t p = 0; p < l_pac; ++p) pac[p >> 2] |= (uint8_t)(rnd(4) << ((~p & 3) << 1));
+		IndexView ix = IndexView();
+		ix.pac = pac; ix.l_pac = l_pac; ix.seq_len = (uint64_t)(2 * l_pac);
+		for (int rep = 0; rep < 8; ++rep) {
+			const int len = 20 + rnd(236), i = rnd(len);
+			const uint64_t t = (uint64_t)rnd((int)(2 * l_pac));
+			std::vector<uint8_t> q((size_t)len + 80, 4);
+			const int m_want = rnd(3) == 0 ? rnd(8) : rnd(140);          // equal bases from (i, t) on, then a difference
+			for (int j = 0; j < len; ++j) q[(size_t)j] = (uint8_t)rnd(4);
+			for (int j = 0; i + j < len && t + (uint64_t)j < ix.seq_len && j <= m_want; ++j) {
+				const int b = ref_base(ix, (int64_t)t + j);
+				q[(size_t)(i + j)] = (uint8_t)(j < m_want ? b : (b + 1 + rnd(3)) & 3);
+			}
+			if (rnd(6) == 0) q[(size_t)(i + rnd(len - i))] = 4;
+			std::vector<uint32_t> rowbuf((size_t)(len + 80) / 8 + 12, 0x44444444u);
+			uint8_t *row = (uint8_t *)rowbuf.data();
+			for (int j = 0; j < len + 72; ++j) { const int b = j < len ? q[(size_t)j] : 4; row[j >> 1] = (uint8_t)((row[j >> 1] & ~(15 << ((j & 1) << 2))) | b << ((j & 1) << 2)); }
+			const uint32_t *w = (const uint32_t *)ix.pac + text_chunk_word(ix, t);
+			bool more_a = false, more_b = false;
+			const int a = text_match_chunk(ix, w[0], w[1], w[2], w[3], t, QBytes{q.data()}, i, len, &more_a);
+			const int b = text_match_chunk(ix, w[0], w[1], w[2], w[3], t, QNibbles{row}, i, len, &more_b);
+			++cases;
+			if (a != b || more_a != more_b) return -cases;
+			// and the base-by-base form against the text itself
+			int m = 0;
+			while (m < a + 1 && i + m < len && t + (uint64_t)m < ix.seq_len && q[(size_t)(i + m)] == ref_base(ix, (int64_t)t + m)) ++m;
+			if (m < a) return -cases;
+			if (m == a + 1 && !more_a) return -cases; // it stopped although the next base is equal, within the read and the text
+		}
+	}
+	return cases;
+}
+
 // the wavefront routines exist on the GPU only (include/arachne_amd.h): nothing to test here
 extern "C" int arx_selftest_wave_sort(int32_t, int32_t, int64_t, int64_t *n_bad) { if (n_bad) *n_bad = 0; return ARX_E_DEVICE; }

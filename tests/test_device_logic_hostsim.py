@@ -152,6 +152,34 @@ def test_dedup_insert_equals_the_general_pass_on_colliding_lists():
     assert nf.value > 5000 and ng.value > 200 and nb.value > 200, (nf.value, ng.value, nb.value)
 
 
+def test_text_mode_word_compare_equals_base_by_base():
+    """Text mode of the first-pass forward extensions (dev_fm.h): the 64-bases-at-a-time comparison of a 4-bit-coded read row with the packed
+    reference (what the wavefront kernels run) against the base-by-base form and the text itself -- both strands, chunk ends at the strand
+    boundary and at the ends of the text, ambiguous bases, reads that end inside a chunk."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    lib = C.CDLL(SIM)
+    lib.arx_test_text_match.restype = C.c_long
+    for seed in (1, 2):
+        assert lib.arx_test_text_match(seed, 15000) == 8 * 15000       # negative: index of the first mismatch
+
+
+def test_text_mode_off_gives_the_same_seeds(env, monkeypatch):
+    """ARX_TEXT_INDEX=0 (no whole suffix array / inverse: every extension base by base, locate by the sampled walk) against the default."""
+    z, ref, o = env
+    seqs, lens = z["reads"][:300], z["lens"][:300]
+    a = ref.batch(seqs, lens).run().fetch()
+    monkeypatch.setenv("ARX_TEXT_INDEX", "0")
+    prefix = workloads.unpack_index(z, tempfile.mkdtemp(prefix="arx_sim_"))
+    ref2 = api.Reference(prefix, lib_path=SIM)
+    b = ref2.batch(seqs, lens).run().fetch()
+    ref2.close()
+    for k in ("reg_off", "regs", "cigars"):
+        assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+    for name in a["alns"].dtype.names:
+        assert (a["alns"][name] == b["alns"][name]).all(), name
+
+
 def test_batch_reset_reuses_the_handle_and_matches_a_fresh_batch():
     """arx_batch_reset: new reads into an existing handle (larger, then smaller than the first set) give what a fresh batch gives."""
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
