@@ -9,4 +9,19 @@ __shared__ unsigned long long rfa_t_prev;
 #include "hip_rt.h"
 #include "api_impl.h"
 
+namespace arx { // register budgets of single thread-per-item kernels (hip_rt.h ItemsWpe), where a measurement backs them
+#ifdef ARX_WPE_CHAIN
+template <> struct ItemsWpe<KChain> { static constexpr int v = ARX_WPE_CHAIN; };
+#endif
+#ifdef ARX_WPE_EXTSTEP
+template <> struct ItemsWpe<KExtStep> { static constexpr int v = ARX_WPE_EXTSTEP; };
+#endif
+#ifdef ARX_WPE_MAPQ
+template <> struct ItemsWpe<KMapq> { static constexpr int v = ARX_WPE_MAPQ; };
+#endif
+#ifdef ARX_WPE_REG2ALN
+template <> struct ItemsWpe<KReg2Aln> { static constexpr int v = ARX_WPE_REG2ALN; };
+#endif
+}
+
 ARX_DEFINE_C_API(arx::HipRT)

@@ -24,7 +24,9 @@ namespace arx {
 #ifndef ARX_ITEMS_WPE
 #define ARX_ITEMS_WPE 1 // (experiments) wavefronts per SIMD the thread-per-item kernels are compiled for
 #endif
-template <class F> __global__ void __launch_bounds__(64, ARX_ITEMS_WPE) k_items(F f, int n)
+// per-functor register budget (wavefronts per SIMD the kernel is compiled for); specialised where a measurement says so
+template <class F> struct ItemsWpe { static constexpr int v = ARX_ITEMS_WPE; };
+template <class F> __global__ void __launch_bounds__(64, ItemsWpe<F>::v) k_items(F f, int n)
 {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	const long long step = (long long)gridDim.x * blockDim.x; // i + step must not wrap: launches of more than 2^30 items exist (arx_open: ARX_SA_DENSE=4 at GRCh38 size)
