@@ -575,8 +575,11 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd2(SeedKArgs
 // group's low lanes through LDS.  Refills are pipelined as in k_seed_bwd2: a group that takes a task loads it in one iteration, its read
 // row and list in the next, riding along with the Occ loads of the groups that extend; one wait on memory per iteration.
 // Tasks whose forward list is longer than 16 go to k_seed_bwd_wave (64 lanes) from their first row.
-// GL = lanes per group (16, 32 or 64): tasks are binned by the length of their forward list (k_bin_tasks) and each bin runs with the
-// smallest group that holds its rows; `list` / `n_list` = the bin's task ids and their number (device memory).
+// GL = lanes per group (16, 21, 32 or 64): tasks are binned by the length of their forward list (k_bin_tasks) and each bin runs with the
+// smallest group that holds its rows; `list` / `n_list` = the bin's task ids and their number (device memory).  GL = 21 (three groups and an
+// idle lane): at GRCh38 size a forward list has an entry for nearly every one of the ~16 depths it takes to get to one occurrence, so more
+// than half of the first pass's lists are 17-20 entries long -- just too long for a quarter of a wavefront, and half a wavefront leaves most
+// of its lanes empty from the first row on.
 template <int GL>
 __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_t *list, const int32_t *n_list, int32_t *counter, int chunk, uint8_t *heavy_flag)
 {
@@ -587,7 +590,8 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 	uint8_t *q_row = lds_g16 + g * A.row;
 	Biv *xch = (Biv *)(lds_g16 + ((NG * A.row + 31) & ~31)) + g * GL;
 	const QNibbles q{q_row};
-	const unsigned long long gmask = GL == 64 ? ~0ull : ((1ull << (GL & 63)) - 1) << (GL * g);
+	const bool in_group = g < NG;                             // (GL = 21: lane 63 belongs to no group; it goes along and never takes a task)
+	const unsigned long long gmask = GL == 64 ? ~0ull : in_group ? ((1ull << (GL & 63)) - 1) << (GL * g) : 0ull;
 	const unsigned long long lowmask = gmask & ((1ull << lane) - 1); // the lanes of this group below this one
 	int stage = 0, t = -1;                                    // group-uniform: 0 idle, 1 task id taken, 2 task loaded, 3 running
 	SeedTask k = SeedTask();
@@ -622,7 +626,7 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 		}
 		if (A.dbg) { ++n_it; n_ext += __builtin_popcountll(__ballot(ext)); }
 		// B. idle groups take tasks
-		const unsigned long long idle = __ballot(stage == 0 && gl == 0);
+		const unsigned long long idle = __ballot(stage == 0 && gl == 0 && in_group);
 		if (idle) {
 			if (pool_next == pool_end && !exhausted) {
 				int base = 0;
@@ -713,19 +717,21 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd_g(SeedKArg
 {
 	seed_bwd_g_body<16>(A, bins, cnt, cnt + 4, 32, heavy_flag);
 	__builtin_amdgcn_wave_barrier();
-	seed_bwd_g_body<32>(A, bins + n, cnt + 1, cnt + 5, 16, heavy_flag);
+	seed_bwd_g_body<21>(A, bins + n, cnt + 1, cnt + 5, 24, heavy_flag);
 	__builtin_amdgcn_wave_barrier();
-	seed_bwd_g_body<64>(A, bins + 2 * (size_t)n, cnt + 2, cnt + 6, 2, heavy_flag);
+	seed_bwd_g_body<32>(A, bins + 2 * (size_t)n, cnt + 2, cnt + 6, 16, heavy_flag);
+	__builtin_amdgcn_wave_barrier();
+	seed_bwd_g_body<64>(A, bins + 3 * (size_t)n, cnt + 3, cnt + 7, 2, heavy_flag);
 }
-// task ids of [t0, t0 + n) by the group size their forward list needs: bins[0] <= 16 entries, [1] <= 32, [2] the rest; cnt[3]
-static __global__ void __launch_bounds__(256) k_bin_tasks(const SeedTask *tasks, int t0, int n, int32_t *bin0, int32_t *bin1, int32_t *bin2, int32_t *cnt)
+// task ids of [t0, t0 + n) by the group size their forward list needs: bins[0] <= 16 entries, [1] <= 21, [2] <= 32, [3] the rest; cnt[4]
+static __global__ void __launch_bounds__(256) k_bin_tasks(const SeedTask *tasks, int t0, int n, int32_t *bin0, int32_t *bin1, int32_t *bin2, int32_t *bin3, int32_t *cnt, int mid)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	const int len = i < n ? tasks[t0 + i].n : 0; // 0: nothing to sweep (nm stays 0)
-	const int cls = len == 0 ? -1 : len <= 16 ? 0 : len <= 32 ? 1 : 2;
-	int32_t *const bins[3] = {bin0, bin1, bin2};
+	const int cls = len == 0 ? -1 : len <= 16 ? 0 : len <= mid ? 1 : len <= 32 ? 2 : 3; // mid = 21 (16: the 21-lane bin stays empty)
+	int32_t *const bins[4] = {bin0, bin1, bin2, bin3};
 #pragma unroll
-	for (int c = 0; c < 3; ++c) { // one atomic per wavefront and bin
+	for (int c = 0; c < 4; ++c) { // one atomic per wavefront and bin
 		const unsigned long long m = __ballot(cls == c);
 		if (!m) continue;
 		int base = 0;

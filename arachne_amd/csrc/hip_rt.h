@@ -175,6 +175,7 @@ struct HipRT {
 	int max_seed_slots() const { return n_cu * seed_bpc * 64; }
 	// the row-parallel backward kernel needs 94 VGPRs: five wavefronts per SIMD fit, not only the four its launch bound asks for, so its grid is
 	// 20 workgroups per CU (4.81 -> 4.62 ms alone; 24 and more lose again, and a build that forces six per SIMD spills: 7.2 ms)
+	int seed_bwd_mid = getenv("ARX_SEED_BWD_MID") ? atoi(getenv("ARX_SEED_BWD_MID")) : 21; // longest list of the 21-lane bin of the backward sweeps (16: none)
 	bool text_bwd = !(getenv("ARX_TEXT_BWD") && atoi(getenv("ARX_TEXT_BWD")) == 0);
 	int seed_bwd_bpc = getenv("ARX_SEED_BWD_BPC") ? atoi(getenv("ARX_SEED_BWD_BPC")) : 20;
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
@@ -401,7 +402,7 @@ struct HipRT {
 		if (!text_bwd) A.ix.isa40 = nullptr; // ARX_TEXT_BWD=0: every sweep walked to its end (k_seed_bwd_g hands nothing to KSeedBwdTail)
 		if (seed_bwd2 == 2 && seed_row <= 132) { // row-parallel sweeps (k_seed_bwd_g<GL>): one task per 16/32/64-lane group, lists in registers
 			uint8_t *flag = alloc<uint8_t>((size_t)n + 8);
-			int32_t *bins = alloc<int32_t>(3 * (size_t)n + 8), *cnt = alloc<int32_t>(8); // cnt[0..2]: bin sizes, cnt[4..6]: the three launches' item counters
+			int32_t *bins = alloc<int32_t>(4 * (size_t)n + 8), *cnt = alloc<int32_t>(8); // cnt[0..3]: bin sizes, cnt[4..7]: the bins' item counters
 			memset0(flag, (size_t)n);
 			memset0(cnt, 32);
 			const int cap = n_cu * seed_bwd_bpc;
@@ -409,11 +410,11 @@ struct HipRT {
 			const size_t xch = 64 * 32;
 			{
 				Scope sc(*this, nm, n);
-				hipLaunchKernelGGL(k_bin_tasks, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.t0, n, bins, bins + n, bins + 2 * (size_t)n, cnt);
+				hipLaunchKernelGGL(k_bin_tasks, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.t0, n, bins, bins + n, bins + 2 * (size_t)n, bins + 3 * (size_t)n, cnt, seed_bwd_mid);
 				hipLaunchKernelGGL(k_seed_bwd_g, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, n, cnt, flag);
 				ARX_HIP_CHECK(hipGetLastError());
 			}
-			if (getenv("ARX_SEED_STATS")) { int32_t h[3]; d2h(h, cnt, 12); fprintf(stderr, "[arx seed stats] backward tasks by list length: <= 16: %d, <= 32: %d, longer: %d\n", h[0], h[1], h[2]); }
+			if (getenv("ARX_SEED_STATS")) { int32_t h[4]; d2h(h, cnt, 16); fprintf(stderr, "[arx seed stats] backward tasks by list length: <= 16: %d, <= %d: %d, <= 32: %d, longer: %d\n", h[0], seed_bwd_mid, h[1], h[2], h[3]); }
 			seed_dbg_report(nm, n);
 			{
 				Scope sc(*this, "seed_bwd_wave", n);

@@ -66,8 +66,8 @@ try:
         return raw * 1024.0 * cal / (disp / launches_per_batch) / reads_per_launch
     traffic = dict(source="rocprofv3 --pmc FETCH_SIZE over `python3 " + "bench.py --no-cpu-baseline --boundary-steps 0" + "` (its own pass, tools/gpu_profile.sh); FETCH_SIZE x 1024 x calibration factor, per seeding-stage run of %d reads" % reads_per_launch,
                    calibration=res.get("fetch_calibration"), workload=bp["config"]["workload"],
-                   bwd_fabric_bytes_per_read=per_read(["k_seed_bwd_g", "k_seed_bwd_g<16>", "k_seed_bwd_g<32>", "k_seed_bwd_g<64>", "k_seed_bwd", "k_seed_bwd2", "k_seed_bwd_wave"], 2.0), fwd_fabric_bytes_per_read=per_read(["k_seed_fwd1", "k_seed_fwd2"], 1.0),
-                   strat_fabric_bytes_per_read=per_read(["k_strat_dyn"], 1.0), locate_fabric_bytes_per_read=per_read(["k_locate_dyn"], 1.0),
+                   bwd_fabric_bytes_per_read=per_read(["k_seed_bwd_g", "k_seed_bwd_g<16>", "k_seed_bwd_g<32>", "k_seed_bwd_g<64>", "k_seed_bwd", "k_seed_bwd2", "k_seed_bwd_wave", "KSeedBwdTail"], 2.0), fwd_fabric_bytes_per_read=per_read(["k_seed_fwd1", "k_seed_fwd2"], 1.0),
+                   strat_fabric_bytes_per_read=per_read(["k_strat_dyn"], 1.0), locate_fabric_bytes_per_read=per_read(["k_locate_dyn", "KLocate"], 1.0),
                    algorithmic=dict(bwd=bp["roofline"]["algorithmic_bytes_per_read"], fwd=bp["roofline_fwd"]["algorithmic_bytes_per_read"],
                                     strat=bp["roofline_strat"]["algorithmic_bytes_per_read"], locate=bp["roofline_locate"]["algorithmic_bytes_per_read"]))
     json.dump(traffic, open(os.path.join(out, "seed_traffic.json"), "w"), indent=1)
@@ -85,7 +85,7 @@ try:
     reads = 2.0 * bp["config"]["pairs_per_step_per_gpu"]
     groups = {"extend": (["k_extend_g16<4>", "k_extend_g16<7>", "k_extend_g16<10>", "k_extend_g16<16>", "k_extend_classes", "k_extend_b16", "k_extend_classes_b"], "cells_extend"),
               "sw_u8": (["k_sw_u8_g16<10>", "k_sw_u8_g16<16>"], "cells_u8"), "reg2aln_nw": (["k_reg2aln_nw_g16"], "cells_global"),
-              "seed_bwd": (["k_seed_bwd_g"], None), "seed_fwd": (["k_seed_fwd1", "k_seed_fwd2"], None), "seed_strat": (["k_strat_dyn"], None), "locate": (["k_locate_dyn"], None)}
+              "seed_bwd": (["k_seed_bwd_g"], None), "seed_fwd": (["k_seed_fwd1", "k_seed_fwd2"], None), "seed_strat": (["k_strat_dyn"], None), "locate": (["k_locate_dyn", "KLocate"], None)}
     swc = {}
     for key, (names, cells_key) in groups.items():
         have = [k for k in names if k in pmc and "SQ_INSTS_VALU" in pmc[k]]
@@ -114,6 +114,6 @@ bt = res.get("bench_plain", {})
 if isinstance(bt, dict):
     print("bench plain:", round(bt.get("value", 0)), "pairs/s; HIP-event avg seed launch", bt.get("roofline", {}).get("avg_launch_ms"))
 print("fetch calibration:", res.get("fetch_calibration"))
-for k in ("k_seed_bwd_g", "k_rescue_heavy", "k_chain_heavy", "k_dedup_heavy", "k_seed_bwd", "k_seed_bwd_wave", "k_seed_fwd1", "k_seed_fwd2", "k_strat_dyn", "k_locate_dyn", "k_sw_u8_g16<10>", "k_extend_g16<4>", "k_reg2aln_nw_g16"):
+for k in ("k_seed_bwd_g", "k_rescue_heavy", "k_chain_heavy", "k_dedup_heavy", "k_seed_bwd", "k_seed_bwd_wave", "k_seed_fwd1", "k_seed_fwd2", "k_strat_dyn", "k_locate_dyn", "KLocate", "KSeedBwdTail", "k_sw_u8_g16<10>", "k_extend_g16<4>", "k_reg2aln_nw_g16"):
     if k in pmc:
         print(k, {a: b for a, b in pmc[k].items()})
