@@ -964,7 +964,11 @@ static int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *
 		end = j + 2 < qlen? j + 2 : qlen;
 	}
 	free(eh);
-	if (cnt) { cnt->cells_extend += cells; ++cnt->n_extend_calls; }
+	if (cnt) {
+		const int rows = i < tlen ? i + 1 : tlen, C = qlen < 32 ? 2 : qlen < 48 ? 3 : qlen < 64 ? 4 : qlen < 96 ? 6 : qlen < 128 ? 8 : qlen < 160 ? 10 : 16;
+		cnt->cells_extend += cells; ++cnt->n_extend_calls;
+		cnt->ext_rows_qlen += (int64_t)rows * qlen; cnt->ext_rows_cols += (int64_t)rows * 16 * C;
+	}
 	*qle_ = max_j + 1; *tle_ = max_i + 1; *gtle_ = max_ie + 1; *gscore_ = gscore; *max_off_ = max_off;
 	return max;
 }

@@ -39,6 +39,7 @@ typedef struct {
 	int64_t n_smem_calls;                    /* bwt_smem1a calls (first pass + re-seeding) */
 	int64_t sa_lf_steps8;                    /* LF steps of the same lookups up to the first row that is a multiple of 8 */
 	int64_t sa_lf_steps4;                    /* ... of 4 (the product's suffix-array sample since round 3) */
+	int64_t ext_rows_qlen, ext_rows_cols;    /* ksw_extend2: rows computed x query length, and x the columns of the device kernel's length class (16 lanes x C) */
 } ora_counters_t;
 
 #ifdef __cplusplus

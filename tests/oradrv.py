@@ -182,7 +182,7 @@ class Oracle:
         return dict(reg_off=off, regs=regs, alns=alns, cigars=cig, secs=secs)
 
     COUNTER_FIELDS = ["n_reads", "ext_same_block", "ext_two_block", "sa_lookups", "sa_lf_steps", "n_regs",
-                      "cells_extend", "cells_u8", "cells_global", "n_extend_calls", "n_u8_calls", "n_global_calls", "ext3_same_block", "ext3_two_block", "extb_same_block", "extb_two_block", "n_smem_calls", "sa_lf_steps8", "sa_lf_steps4"]
+                      "cells_extend", "cells_u8", "cells_global", "n_extend_calls", "n_u8_calls", "n_global_calls", "ext3_same_block", "ext3_two_block", "extb_same_block", "extb_two_block", "n_smem_calls", "sa_lf_steps8", "sa_lf_steps4", "ext_rows_qlen", "ext_rows_cols"]
 
     def counters(self, reset=False):
         buf = np.zeros(len(self.COUNTER_FIELDS), dtype=np.int64)
