@@ -414,6 +414,15 @@ struct HipRT {
 				hipLaunchKernelGGL(k_seed_bwd_g, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, n, cnt, flag);
 				ARX_HIP_CHECK(hipGetLastError());
 			}
+			if (getenv("ARX_SEED_HIST")) { // diagnostics: forward-list lengths of this launch's tasks
+				std::vector<SeedTask> ht((size_t)n);
+				d2h(ht.data(), f.P.tasks + f.t0, (size_t)n * sizeof(SeedTask));
+				long long hist[40] = {0};
+				for (auto &k : ht) ++hist[k.n < 39 ? k.n : 39];
+				fprintf(stderr, "[arx seed hist] %d tasks, list lengths 0..39+:", n);
+				for (int i = 0; i < 40; ++i) fprintf(stderr, " %lld", hist[i]);
+				fprintf(stderr, "\n");
+			}
 			if (getenv("ARX_SEED_STATS")) { int32_t h[4]; d2h(h, cnt, 16); fprintf(stderr, "[arx seed stats] backward tasks by list length: <= 16: %d, <= %d: %d, <= 32: %d, longer: %d\n", h[0], seed_bwd_mid, h[1], h[2], h[3]); }
 			seed_dbg_report(nm, n);
 			{
