@@ -164,6 +164,12 @@ def test_text_mode_word_compare_equals_base_by_base():
         assert lib.arx_test_text_match(seed, 15000) == 8 * 15000       # negative: index of the first mismatch
 
 
+def test_index_info(env):
+    z, ref, o = env
+    info = ref.index_info()
+    assert info["symbols"] > 0 and info["text_mode"] and info["sa_rows_per_entry"] == 1 and info["kmer_k"] >= 4 and info["kmer_fwd_depth"] == min(info["kmer_k"], 14)
+
+
 def test_text_mode_off_gives_the_same_seeds(env, monkeypatch):
     """ARX_TEXT_INDEX=0 (no whole suffix array / inverse: every extension base by base, locate by the sampled walk) against the default."""
     z, ref, o = env
@@ -172,6 +178,7 @@ def test_text_mode_off_gives_the_same_seeds(env, monkeypatch):
     monkeypatch.setenv("ARX_TEXT_INDEX", "0")
     prefix = workloads.unpack_index(z, tempfile.mkdtemp(prefix="arx_sim_"))
     ref2 = api.Reference(prefix, lib_path=SIM)
+    assert not ref2.index_info()["text_mode"] and ref2.index_info()["sa_rows_per_entry"] == 4
     b = ref2.batch(seqs, lens).run().fetch()
     ref2.close()
     for k in ("reg_off", "regs", "cigars"):

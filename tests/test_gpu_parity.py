@@ -180,6 +180,35 @@ def test_other_read_lengths_take_the_wide_kernel_variants(built, read_len, mixed
     ref.close()
 
 
+def test_index_info_and_the_sampled_suffix_array_fallback(built, monkeypatch):
+    """arx_index_info reports what arx_open built; with ARX_TEXT_INDEX=0 (what a device short of memory gets by itself: no whole suffix array, no
+    inverse, every extension base by base, locate by the walk to the sample every 4th row) the results are the same."""
+    import oradrv
+    g, rs, seqs, lens = workloads.long_reads(150, n_bc=3, ppb=300)
+    tmp = tempfile.mkdtemp(prefix="arx_gpu_info_")
+    prefix = os.path.join(tmp, "g.fa")
+    g.write_fasta(prefix)
+    api.index_build(prefix, prefix)
+    ref = api.load_reference(prefix, 0)
+    info = ref.index_info()
+    assert info["symbols"] == 2 * 1_200_000 and info["text_mode"] and info["sa_rows_per_entry"] == 1 and info["kmer_k"] == 10 and info["kmer_fwd_depth"] == 10
+    assert info["device_bytes"] > 2 * 5 * info["symbols"]
+    a = ref.batch(seqs, lens).run().fetch()
+    ref.close()
+    monkeypatch.setenv("ARX_TEXT_INDEX", "0")
+    ref = api.load_reference(prefix, 0)
+    info = ref.index_info()
+    assert not info["text_mode"] and info["sa_rows_per_entry"] == 4
+    b = ref.batch(seqs, lens).run().fetch()
+    ref.close()
+    o = oradrv.Oracle(prefix)
+    parity.check_final(a, o.batch(seqs, lens, n_threads=8))
+    for k in ("reg_off", "regs", "cigars"):
+        assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+    for name in a["alns"].dtype.names:
+        assert (a["alns"][name] == b["alns"][name]).all(), name
+
+
 def test_reads_of_256_bases_are_refused(built):
     from arachne_amd import synth
     g = synth.make_genome(5, [300_000])
