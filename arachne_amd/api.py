@@ -67,6 +67,8 @@ def _load(path):
     lib.arx_last_error.argtypes = [vp]
     lib.arx_backend.restype = C.c_char_p
     lib.arx_index_info.argtypes = [vp, vp]
+    lib.arx_host_register.argtypes = [vp, C.c_int64]
+    lib.arx_host_unregister.argtypes = [vp]
     lib.arx_contigs.argtypes = [vp] + [vp] * 6
     lib.arx_batch_create.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
     lib.arx_batch_reset.argtypes = [vp, vp, i32, vp, vp]
@@ -176,6 +178,14 @@ class Batch:
             out["cands"] = (v.cands, v.n_cands, CAND_DTYPE)
         return out
 
+    def pin(self, arr):
+        """arx_host_register on a numpy array the caller keeps reusing (inputs of reset(), buffers of fetch_into()); released when the array is
+        collected.  Returns the array; silently leaves it pageable when the registration is refused."""
+        import weakref
+        if arr.nbytes and self.ref.lib.arx_host_register(arr.ctypes.data, arr.nbytes) == 0:
+            weakref.finalize(arr, self.ref.lib.arx_host_unregister, arr.ctypes.data)
+        return arr
+
     def fetch_into(self, buf):
         """arx_batch_fetch + arx_batch_rfa_fetch into arrays the caller keeps (buf: dict with reg_off, regs, alns, cigars, cand_off, cands,
         each at least as long as this batch needs; grown here when not): what a steady-state caller does, no allocation per batch."""
@@ -184,7 +194,8 @@ class Batch:
                     cand_off=(self.n_reads + 1, np.int32), cands=(self._n_cands, CAND_DTYPE))
         for k, (n, dt) in need.items():
             if k not in buf or len(buf[k]) < n:
-                buf[k] = np.zeros(int(n * 1.2) + 16, dtype=dt)
+                buf[k] = None                                            # (the old array's finalizer unregisters it)
+                buf[k] = self.pin(np.zeros(int(n * 1.2) + 16, dtype=dt))   # page-locked: the results arrive by DMA, no staging copy
         self.ref._check(self.ref.lib.arx_batch_fetch(self.ref.h, self.h, buf["reg_off"].ctypes.data, buf["regs"].ctypes.data, buf["alns"].ctypes.data, buf["cigars"].ctypes.data))
         if self._n_cands:
             self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, buf["cand_off"].ctypes.data, buf["cands"].ctypes.data))
@@ -195,7 +206,8 @@ class Batch:
         n = C.c_int64()
         self.ref._check(self.ref.lib.arx_batch_post(self.ref.h, self.h, C.byref(n)))
         if "post" not in buf or len(buf["post"]) < self._n_cands:
-            buf["post"] = np.zeros(int(self._n_cands * 1.2) + 16, dtype=POST_DTYPE)
+            buf["post"] = None
+            buf["post"] = self.pin(np.zeros(int(self._n_cands * 1.2) + 16, dtype=POST_DTYPE))
         self.ref._check(self.ref.lib.arx_batch_post_fetch(self.ref.h, self.h, buf["post"].ctypes.data, None, None, None))
         return buf["post"]
 

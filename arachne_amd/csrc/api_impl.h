@@ -267,6 +267,8 @@ template <class RT> struct Batch {
 		return g_open_error.c_str();                                                                                                \
 	}                                                                                                                               \
 	const char *arx_backend(void) { return RT::name(); }                                                                            \
+	int arx_host_register(void *p, int64_t bytes) { return p && bytes > 0 && RT::host_register(p, (size_t)bytes) == 0 ? ARX_OK : ARX_E_ARG; } \
+	int arx_host_unregister(void *p) { return p && RT::host_unregister(p) == 0 ? ARX_OK : ARX_E_ARG; }                              \
 	int arx_index_info(arx_ctx *h, int64_t *info)                                                                                   \
 	{                                                                                                                               \
 		Ctx *c = (Ctx *)h;                                                                                                          \

@@ -155,6 +155,22 @@ struct HipRT {
 		return stage_buf;
 	}
 	void h2d_staged(void *d, const void *staged, size_t bytes) { if (bytes) ARX_HIP_CHECK(hipMemcpyAsync(d, staged, bytes, hipMemcpyHostToDevice, stream)); }
+	// Host memory the caller has page-locked (arx_host_register): copies to and from it are DMA at PCIe speed without a staging copy --
+	// hipMemcpyAsync finds that out by itself for the results (d2h); an upload from it skips the runtime's own pinned staging buffer.
+	static int host_register(void *p, size_t bytes) { const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable); if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess ? 0 : -1; }
+	static int host_unregister(void *p) { const hipError_t e = hipHostUnregister(p); if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess ? 0 : -1; }
+	static bool host_pinned(const void *p)
+	{
+		hipPointerAttribute_t a;
+		if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+		return a.type == hipMemoryTypeHost;
+	}
+	void h2d_pinned(void *d, const void *s, size_t bytes) // from page-locked caller memory; returns when the copy is done (the caller may reuse the array)
+	{
+		if (!bytes) return;
+		ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream));
+		ARX_HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	uint64_t free_bytes() const { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? (uint64_t)f : 0; }
 	void d2d(void *d, const void *s, size_t bytes) { if (bytes) ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
 	void memset0(void *d, size_t bytes) { ARX_HIP_CHECK(hipMemsetAsync(d, 0, bytes, stream)); }

@@ -486,14 +486,15 @@ public:
 			b.base_off = rt.template palloc<int32_t>((size_t)b.cap_reads); b.lens = rt.template palloc<int32_t>((size_t)b.cap_reads);
 		}
 		b.n_reads = n_reads; b.n_bases = tot; b.max_len = mx;
-		uint8_t *st = (uint8_t *)rt.stage((size_t)tot + 8 * ((size_t)n_reads + 2));
-		int32_t *st_off = (int32_t *)(st + (((size_t)tot + 7) & ~(size_t)7)), *st_len = st_off + n_reads + 1;
-		memcpy(st, bases, (size_t)tot);
+		const bool direct = tot > 0 && RT::host_pinned(bases); // page-locked by the caller (arx_host_register): the bases go as they lie, no staging copy
+		uint8_t *st = (uint8_t *)rt.stage((direct ? 0 : (size_t)tot) + 8 * ((size_t)n_reads + 2) + 8);
+		int32_t *st_off = (int32_t *)(st + (direct ? 0 : (((size_t)tot + 7) & ~(size_t)7))), *st_len = st_off + n_reads + 1;
+		if (!direct) memcpy(st, bases, (size_t)tot);
 		int64_t run = 0;
 		for (int i = 0; i < n_reads; ++i) { st_off[i] = (int32_t)run; run += lens[i]; }
 		st_off[n_reads] = (int32_t)run;
 		memcpy(st_len, lens, sizeof(int32_t) * (size_t)n_reads);
-		rt.h2d_staged(b.bases, st, (size_t)tot);
+		if (direct) rt.h2d_pinned(b.bases, bases, (size_t)tot); else rt.h2d_staged(b.bases, st, (size_t)tot);
 		rt.h2d_staged(b.base_off, st_off, sizeof(int32_t) * ((size_t)n_reads + 1));
 		rt.h2d_staged(b.lens, st_len, sizeof(int32_t) * (size_t)n_reads);
 	}

@@ -339,7 +339,7 @@ def main():
                 end += 1
             p0, p1 = int(po[start]), int(po[end])
             b = ref.batch(rs.seqs[2 * p0:2 * p1], rs.lens[2 * p0:2 * p1])
-            b.host = (np.ascontiguousarray(rs.seqs[2 * p0:2 * p1]).reshape(-1), np.ascontiguousarray(rs.lens[2 * p0:2 * p1]))
+            b.host = (b.pin(np.array(rs.seqs[2 * p0:2 * p1], copy=True).reshape(-1)), np.ascontiguousarray(rs.lens[2 * p0:2 * p1]))   # the caller's own, page-locked read buffer
             b.out = {}
             b.bc_pair_off = (po[start:end + 1] - po[start]).astype(np.int64)
             b.do_rfa = np.array([api.worth_running_rfa(rs.barcodes[i], int(po[i + 1] - po[i])) for i in range(start, end)], dtype=np.uint8)
@@ -355,6 +355,8 @@ def main():
     pool = ThreadPoolExecutor(max_workers=len(batches) * len(sets))   # one host thread per batch handle (the staggered schedule needs them all alive)
 
     import threading
+    phase_lock = threading.Lock()
+    phase_s = {False: {}, True: {}}    # host-side seconds per phase of a batch's pass, summed over batches (resident / boundary passes)
 
     def run_steps(n_steps, boundary=False):
         """n_steps passes over the whole read set (boundary: every pass hands the reads over from host memory and takes the results back).  Every batch runs start to end on its own stream and host thread; the seeding
@@ -391,21 +393,32 @@ def main():
                             if args.post:
                                 b.post(fetch=False)
                     continue
+                tp = [time.time()]
                 if boundary:
-                    b.reset(*b.host)                      # reads come from host memory: pinned staging + async copies on the batch's stream
+                    b.reset(*b.host)                      # reads come from host memory the caller page-locked (arx_host_register): DMA on the batch's stream
+                tp.append(time.time())
                 if i > 0:
                     wait_for(seeded[s_][i - 1])
                 elif s_ > 0:
                     wait_for(seeded[s_ - 1][nb - 1])
+                tp.append(time.time())
                 b.run(api.STAGE_SEED)
                 seeded[s_][i].set()
+                tp.append(time.time())
                 b.run(api.STAGE_ALN)
+                tp.append(time.time())
                 if not args.no_rfa:
                     b.rfa(b.bc_pair_off, b.do_rfa, fetch=False)
                     if args.post:
                         b.post(fetch=False)
+                tp.append(time.time())
                 if boundary:
                     b.fetch_into(b.out)                   # regions, alignment records, CIGARs, placed candidates with MAPQ back in host memory
+                tp.append(time.time())
+                with phase_lock:
+                    for k_, (a_, b_) in zip(("reset", "wait_turn", "seed", "align", "rfa", "fetch"), zip(tp, tp[1:])):
+                        phase_s[boundary][k_] = phase_s[boundary].get(k_, 0.0) + (b_ - a_)
+                    phase_s[boundary]["batches"] = phase_s[boundary].get("batches", 0) + 1
         list(pool.map(worker, range(nb * len(sets))))
 
     # every handle's first run obtains its work memory (hipMalloc of tens of GB: seconds beside a 69 GB k-mer table): part of the set-up like
@@ -420,6 +433,7 @@ def main():
                     b.post(fetch=False)
     setup["prime_handles_s"] = round(time.time() - t, 2)
     run_steps(args.warmup)
+    phase_s[False].clear()
     ref.kernel_times_reset(True)   # HIP events around every launch on the launch stream, resolved after the timed region
     barrier()
     t0 = time.time()
@@ -438,6 +452,7 @@ def main():
     if args.boundary_steps > 0 and args.stagger:
         ref.kernel_times_reset(False)
         run_steps(1, boundary=True)                       # sizes the reused host arrays and the staging
+        phase_s[True].clear()
         barrier()
         tb = time.time()
         run_steps(args.boundary_steps, boundary=True)
@@ -537,8 +552,15 @@ def main():
             out["boundary"] = dict(value=pairs_per_step * args.boundary_steps / boundary, unit="paired reads/s", steps=args.boundary_steps,
                                    ms_per_step=1000.0 * boundary / args.boundary_steps,
                                    host_bytes_in_per_pair=round(float(rs.lens.sum()) / rs.n_pairs + 8, 1), host_bytes_out_per_pair=round(out_bytes / rs.n_pairs, 1),
-                                   note="same steps timed from host arrays in (arx_batch_reset: pinned staging, async H2D on the batch's stream, handle and work memory "
-                                        "reused) to host arrays out (arx_batch_fetch + arx_batch_rfa_fetch into arrays the caller reuses); PCIe-inclusive, never `value`")
+                                   note="same steps timed from host arrays in (arx_batch_reset from the caller's page-locked read buffer, arx_host_register: DMA on the "
+                                        "batch's stream, handle and work memory reused) to host arrays out (arx_batch_fetch + arx_batch_rfa_fetch into page-locked arrays "
+                                        "the caller reuses); PCIe-inclusive, never `value`")
+        def per_batch(d):
+            n = max(d.get("batches", 0), 1)
+            return {k: round(1000.0 * v / n, 1) for k, v in d.items() if k != "batches"}
+        out["host_phase_ms_per_batch"] = dict(resident=per_batch(phase_s[False]), boundary=per_batch(phase_s[True]),
+                                              note="wall time of a batch's host thread per phase (three batches in flight: the phases of different batches overlap); "
+                                                   "wait_turn = waiting for the batch ahead to leave the seeding stage (the staggered schedule)")
         # where the FM-index lives decides what the seeding kernels are bound by: a table under 256 MiB stays in the Infinity Cache
         occ_bytes = index_bytes["bwt"]
         in_hbm = occ_bytes > INFINITY_CACHE_BYTES

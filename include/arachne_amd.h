@@ -71,6 +71,14 @@ const char *arx_backend(void);                 /* "hip:gfx950" for the product l
  * (text mode of the seeding passes); [5] bytes of device memory the index holds; [6], [7] reserved (0) */
 int arx_index_info(arx_ctx *ctx, int64_t *info /* 8 */);
 
+/* Page-locks host memory the caller hands to arx_batch_create / arx_batch_reset (bases) or receives results in (arx_batch_fetch,
+ * arx_batch_rfa_fetch, arx_batch_post_fetch), for as long as it keeps reusing those arrays: copies then run at PCIe speed without a
+ * staging copy (the reference recycles its per-work-unit buffers the same way, aligner.go:234 ReturnBuffer, gobwa.go:107-126 Arena).
+ * Optional: unregistered memory works, through the library's own staging.  Unregister before freeing.  ARX_E_ARG when the range cannot
+ * be (un)registered (e.g. registered already). */
+int arx_host_register(void *ptr, int64_t bytes);
+int arx_host_unregister(void *ptr);
+
 int arx_contigs(arx_ctx *ctx, int32_t *n, const char *const **names, const int64_t **offsets, const int32_t **lens,
                 const int32_t **is_alt, int64_t *l_pac);
 

@@ -121,6 +121,10 @@ struct SimRT {
 	std::vector<uint8_t> stage_mem;
 	void *stage(size_t bytes) { stage_mem.assign(bytes + 8, 0xCD); return stage_mem.data(); }
 	void h2d_staged(void *d, const void *s, size_t bytes) { memcpy(d, s, bytes); }
+	static int host_register(void *, size_t) { return 0; }
+	static int host_unregister(void *) { return 0; }
+	static bool host_pinned(const void *) { return false; }
+	void h2d_pinned(void *d, const void *s, size_t bytes) { memcpy(d, s, bytes); }
 	template <class T> T *palloc(size_t n) { return alloc<T>(n); }
 	void pfree(void *p) { ::free(p); }
 	void arena_reset() {}
