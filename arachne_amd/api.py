@@ -68,6 +68,8 @@ def _load(path):
     lib.arx_backend.restype = C.c_char_p
     lib.arx_index_info.argtypes = [vp, vp]
     lib.arx_host_register.argtypes = [vp, C.c_int64]
+    lib.arx_batch_detach.argtypes = [vp, vp, vp]
+    lib.arx_batch_fetch_detached.argtypes = [vp] * 8
     lib.arx_host_unregister.argtypes = [vp]
     lib.arx_contigs.argtypes = [vp] + [vp] * 6
     lib.arx_batch_create.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
@@ -200,6 +202,25 @@ class Batch:
         if self._n_cands:
             self.ref._check(self.ref.lib.arx_batch_rfa_fetch(self.ref.h, self.h, buf["cand_off"].ctypes.data, buf["cands"].ctypes.data))
         return c
+
+    def detach(self):
+        """arx_batch_detach: the results copied aside on the device; the handle is free for reset() / run() while another thread calls
+        fetch_detached_into().  -> sizes dict"""
+        a = np.zeros(4, dtype=np.int64)
+        self.ref._check(self.ref.lib.arx_batch_detach(self.ref.h, self.h, a.ctypes.data))
+        return dict(n_reads=int(a[0]), n_regs=int(a[1]), n_cigar=int(a[2]), n_cands=int(a[3]))
+
+    def fetch_detached_into(self, buf, sizes):
+        """arx_batch_fetch_detached into arrays the caller keeps (grown and page-locked here when needed), from any thread."""
+        need = dict(reg_off=(sizes["n_reads"] + 1, np.int32), regs=(sizes["n_regs"], REG_DTYPE), alns=(sizes["n_regs"], ALN_DTYPE), cigars=(max(sizes["n_cigar"], 1), np.uint32),
+                    cand_off=(sizes["n_reads"] + 1, np.int32), cands=(max(sizes["n_cands"], 1), CAND_DTYPE))
+        for k, (n, dt) in need.items():
+            if k not in buf or len(buf[k]) < n:
+                buf[k] = None
+                buf[k] = self.pin(np.zeros(int(n * 1.2) + 16, dtype=dt))
+        self.ref._check(self.ref.lib.arx_batch_fetch_detached(self.ref.h, self.h, buf["reg_off"].ctypes.data, buf["regs"].ctypes.data, buf["alns"].ctypes.data,
+                                                              buf["cigars"].ctypes.data, buf["cand_off"].ctypes.data, buf["cands"].ctypes.data))
+        return sizes
 
     def post_into(self, buf):
         """arx_batch_post + arx_batch_post_fetch of the per-candidate records into buf["post"] (grown when needed)."""

@@ -203,6 +203,15 @@ template <class RT> struct Batch {
 	RfaResult rfa;
 	PostResult post; std::vector<size_t> post_mark;
 	std::vector<size_t> rfa_mark; bool rfa_marked = false; // arena state after ARX_STAGE_ALN: a repeated arx_batch_rfa reuses the same memory
+	// arx_batch_detach: the dense results copied aside (device memory of their own, outside the work arena) so that the handle can take its
+	// next reads while a second host thread takes them home through a stream of its own (arx_batch_fetch_detached)
+	struct Detached {
+		bool valid = false; int32_t n_reads = 0; int64_t n_regs = 0, n_cig = 0, n_cands = 0;
+		size_t o_reg_off = 0, o_regs = 0, o_alns = 0, o_cig = 0, o_cands = 0;
+		std::vector<int32_t> cand_off;
+	} det;
+	char *slab = nullptr; size_t slab_cap = 0;
+	RT rt_copy; bool copy_ready = false;
 	explicit Batch(Context<RT> *c) : ctx(c), pipe(rt, c->ix)
 	{
 		std::string e = rt.init(c->device);
@@ -214,6 +223,7 @@ template <class RT> struct Batch {
 	{
 		rt.bind();
 		pipe.free_work(work); pipe.release(db);
+		if (slab) rt.pfree(slab);
 		std::lock_guard<std::mutex> g(ctx->mu);
 		for (auto &kv : rt.timers()) { KernelTimer &t = ctx->tm_done[kv.first]; t.ms += kv.second.ms; t.calls += kv.second.calls; t.items += kv.second.items; }
 		ctx->live.erase(this);
@@ -331,6 +341,50 @@ template <class RT> struct Batch {
 		v->reg_off = b->work.c_reg_off; v->regs = (const arx_reg *)b->work.c_regs; v->alns = (const arx_aln *)b->work.c_alns; v->cigars = b->work.c_cig; \
 		const bool placed = b->rfa_marked && !b->rfa.cand_off.empty();                                                              \
 		v->n_cands = placed ? b->rfa.n_cands : 0; v->cand_off = placed ? b->rfa.d_cand_off : nullptr; v->cands = placed ? (const arx_cand *)b->rfa.d_cands : nullptr; \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_detach(arx_ctx *h, arx_batch *bh, int64_t *sizes)                                                                 \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->work.alns) { c->set_error("arx_batch_detach before arx_batch_run(ARX_STAGE_ALN)"); return ARX_E_ARG; }              \
+		ARX_TRY(c, b->rt.bind();                                                                                                    \
+			auto &d = b->det; d.valid = false;                                                                                      \
+			const bool placed = b->rfa_marked && !b->rfa.cand_off.empty();                                                          \
+			d.n_reads = b->db.n_reads; d.n_regs = b->work.c_n_regs; d.n_cig = b->work.c_n_cig; d.n_cands = placed ? b->rfa.n_cands : 0; \
+			auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };                                                            \
+			size_t at = 0;                                                                                                          \
+			d.o_reg_off = at; at += al(4 * ((size_t)d.n_reads + 1));                                                                \
+			d.o_regs = at; at += al(sizeof(arx::Reg) * (size_t)d.n_regs);                                                           \
+			d.o_alns = at; at += al(sizeof(arx::Aln) * (size_t)d.n_regs);                                                           \
+			d.o_cig = at; at += al(4 * (size_t)d.n_cig);                                                                            \
+			d.o_cands = at; at += al(sizeof(arx::Cand) * (size_t)d.n_cands);                                                        \
+			if (at > b->slab_cap) { b->rt.sync(); if (b->slab) b->rt.pfree(b->slab); b->slab_cap = at + at / 4 + 4096; b->slab = b->rt.template palloc<char>(b->slab_cap); } \
+			b->rt.d2d(b->slab + d.o_reg_off, b->work.c_reg_off, 4 * ((size_t)d.n_reads + 1));                                       \
+			b->rt.d2d(b->slab + d.o_regs, b->work.c_regs, sizeof(arx::Reg) * (size_t)d.n_regs);                                     \
+			b->rt.d2d(b->slab + d.o_alns, b->work.c_alns, sizeof(arx::Aln) * (size_t)d.n_regs);                                     \
+			b->rt.d2d(b->slab + d.o_cig, b->work.c_cig, 4 * (size_t)d.n_cig);                                                       \
+			if (placed) { b->rt.d2d(b->slab + d.o_cands, b->rfa.d_cands, sizeof(arx::Cand) * (size_t)d.n_cands); d.cand_off = b->rfa.cand_off; } \
+			else d.cand_off.clear();                                                                                                \
+			b->rt.sync();                                                                                                           \
+			d.valid = true;                                                                                                         \
+			if (sizes) { sizes[0] = d.n_reads; sizes[1] = d.n_regs; sizes[2] = d.n_cig; sizes[3] = d.n_cands; })                    \
+		return ARX_OK;                                                                                                              \
+	}                                                                                                                               \
+	int arx_batch_fetch_detached(arx_ctx *h, arx_batch *bh, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars, int32_t *cand_off, arx_cand *cands) \
+	{                                                                                                                               \
+		Ctx *c = (Ctx *)h; Bat *b = (Bat *)bh;                                                                                      \
+		if (!b->det.valid) { c->set_error("arx_batch_fetch_detached before arx_batch_detach"); return ARX_E_ARG; }                  \
+		ARX_TRY(c,                                                                                                                  \
+			if (!b->copy_ready) { std::string e = b->rt_copy.init(c->device); if (!e.empty()) throw std::runtime_error(e); b->copy_ready = true; } \
+			b->rt_copy.bind();                                                                                                      \
+			const auto &d = b->det;                                                                                                 \
+			if (reg_off) b->rt_copy.d2h_async(reg_off, b->slab + d.o_reg_off, 4 * ((size_t)d.n_reads + 1));                         \
+			if (regs) b->rt_copy.d2h_async(regs, b->slab + d.o_regs, sizeof(arx::Reg) * (size_t)d.n_regs);                          \
+			if (alns) b->rt_copy.d2h_async(alns, b->slab + d.o_alns, sizeof(arx::Aln) * (size_t)d.n_regs);                          \
+			if (cigars) b->rt_copy.d2h_async(cigars, b->slab + d.o_cig, 4 * (size_t)d.n_cig);                                       \
+			if (cands && d.n_cands) b->rt_copy.d2h_async(cands, b->slab + d.o_cands, sizeof(arx::Cand) * (size_t)d.n_cands);        \
+			if (cand_off && !d.cand_off.empty()) memcpy(cand_off, d.cand_off.data(), 4 * ((size_t)d.n_reads + 1));                  \
+			b->rt_copy.sync();)                                                                                                     \
 		return ARX_OK;                                                                                                              \
 	}                                                                                                                               \
 	int arx_batch_run(arx_ctx *h, arx_batch *bh, int32_t last_stage)                                                                \

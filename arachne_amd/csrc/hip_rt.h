@@ -141,6 +141,7 @@ struct HipRT {
 		ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream));
 		ARX_HIP_CHECK(hipStreamSynchronize(stream));
 	}
+	void d2h_async(void *d, const void *s, size_t bytes) { if (bytes) ARX_HIP_CHECK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream)); } // sync() before the data is read
 	// staging for uploads: pinned host memory owned by the runtime, grown on demand.  stage() waits for the copies of the previous
 	// use (the stream has long passed them when a batch is reset after its results were fetched); h2d_staged() only enqueues.
 	void *stage_buf = 0; size_t stage_cap = 0;

@@ -251,8 +251,9 @@ def main():
     ap.add_argument("--no-rfa", action="store_true", help="(diagnostics) stop after CIGAR generation")
     ap.add_argument("--post", action="store_true", help="also run the passes between placement and the BAM records in the step (CIGAR walk with "
                     "mismatch locations, markDuplicates, split reads: SURVEY.md s8f-3)")
-    ap.add_argument("--boundary-steps", type=int, default=3, help="extra steps timed boundary to boundary (host reads in through arx_batch_reset, "
-                    "results out through arx_batch_fetch + arx_batch_rfa_fetch into reused host arrays); 0: skip.  Reported under `boundary`, never as `value`")
+    ap.add_argument("--boundary-steps", type=int, default=12, help="extra steps timed boundary to boundary (host reads in through arx_batch_reset, "
+                    "results out through arx_batch_detach + arx_batch_fetch_detached into reused page-locked host arrays); 0: skip.  Reported under `boundary`, never "
+                    "as `value`.  Several steps per handle: with one step per handle (3 until the end of round 3) the figure is the latency of one batch, not a rate")
     ap.add_argument("--scatter-steps", type=int, default=0, help="N > 1: extra steps run as SURVEY.md s8e's dataflow -- rank 0 owns every rank's barcodes, assigns whole "
                     "barcodes by pair count (LPT), scatters the packed batches and gathers the result slabs over torch.distributed point-to-point (RCCL / xGMI) "
                     "inside the timed steps; reported under `scatter_gather` (an ingest rank cannot feed 8 GPUs at kernel rate: see DESIGN.md s6)")
@@ -355,6 +356,7 @@ def main():
     pool = ThreadPoolExecutor(max_workers=len(batches) * len(sets))   # one host thread per batch handle (the staggered schedule needs them all alive)
 
     import threading
+    fetch_pool = ThreadPoolExecutor(max_workers=len(batches) * len(sets))   # the second host thread of every handle (boundary pass: results home while the next reads run)
     phase_lock = threading.Lock()
     phase_s = {False: {}, True: {}}    # host-side seconds per phase of a batch's pass, summed over batches (resident / boundary passes)
 
@@ -413,13 +415,24 @@ def main():
                         b.post(fetch=False)
                 tp.append(time.time())
                 if boundary:
-                    b.fetch_into(b.out)                   # regions, alignment records, CIGARs, placed candidates with MAPQ back in host memory
+                    # regions, alignment records, CIGARs, placed candidates with MAPQ back in host memory: copied aside on the device (arx_batch_detach),
+                    # then taken home by a second thread (arx_batch_fetch_detached, its own stream) while this one goes on with the next reads
+                    if os.environ.get("ARX_BENCH_SYNC_FETCH"):        # (A/B: the handle's own thread takes them home before it goes on)
+                        b.fetch_into(b.out)
+                    else:
+                        if getattr(b, "pending", None) is not None:
+                            b.pending.result()
+                        b.pending = fetch_pool.submit(b.fetch_detached_into, b.out, b.detach())
                 tp.append(time.time())
                 with phase_lock:
                     for k_, (a_, b_) in zip(("reset", "wait_turn", "seed", "align", "rfa", "fetch"), zip(tp, tp[1:])):
                         phase_s[boundary][k_] = phase_s[boundary].get(k_, 0.0) + (b_ - a_)
                     phase_s[boundary]["batches"] = phase_s[boundary].get("batches", 0) + 1
         list(pool.map(worker, range(nb * len(sets))))
+        for bs_ in sets:                                      # the last results are home before the clock stops
+            for b_ in bs_:
+                if getattr(b_, "pending", None) is not None:
+                    b_.pending.result(); b_.pending = None
 
     # every handle's first run obtains its work memory (hipMalloc of tens of GB: seconds beside a 69 GB k-mer table): part of the set-up like
     # the upload of the reads, whatever --warmup says
@@ -553,8 +566,8 @@ def main():
                                    ms_per_step=1000.0 * boundary / args.boundary_steps,
                                    host_bytes_in_per_pair=round(float(rs.lens.sum()) / rs.n_pairs + 8, 1), host_bytes_out_per_pair=round(out_bytes / rs.n_pairs, 1),
                                    note="same steps timed from host arrays in (arx_batch_reset from the caller's page-locked read buffer, arx_host_register: DMA on the "
-                                        "batch's stream, handle and work memory reused) to host arrays out (arx_batch_fetch + arx_batch_rfa_fetch into page-locked arrays "
-                                        "the caller reuses); PCIe-inclusive, never `value`")
+                                        "batch's stream, handle and work memory reused) to host arrays out (arx_batch_detach, then arx_batch_fetch_detached by the handle's second host thread into page-locked "
+                                        "arrays the caller reuses, while the handle takes its next reads); PCIe-inclusive, never `value`")
         def per_batch(d):
             n = max(d.get("batches", 0), 1)
             return {k: round(1000.0 * v / n, 1) for k, v in d.items() if k != "batches"}

@@ -132,6 +132,15 @@ int arx_batch_rfa(arx_ctx *ctx, arx_batch *b, int32_t n_barcodes, const int64_t 
                   const int64_t *cen_start, const int64_t *cen_end, int64_t *n_cands);
 int arx_batch_rfa_fetch(arx_ctx *ctx, arx_batch *b, int32_t *cand_off /* n_reads+1 */, arx_cand *cands /* n_cands */);
 
+/* Overlapping the way home with the next super-batch (a worker with two host threads per handle).  arx_batch_detach copies the dense results of
+ * the run -- and of arx_batch_rfa when it has run -- aside on the device (memory of the handle's own, outside its work memory; < 1 ms) and says
+ * how large they are: sizes[0..3] = reads, regions, CIGAR words, candidates.  From then on the handle may be reset and run again by one thread
+ * while ANOTHER thread calls arx_batch_fetch_detached, which copies them to host arrays on a stream of its own (any pointer may be NULL: not
+ * wanted).  The next arx_batch_detach of the same handle must wait until that call has returned (the caller's ordering).  The reference's
+ * workers overlap the same way: results of one work unit are written out while the next is aligned (aligner.go:335-371). */
+int arx_batch_detach(arx_ctx *ctx, arx_batch *b, int64_t *sizes /* 4 */);
+int arx_batch_fetch_detached(arx_ctx *ctx, arx_batch *b, int32_t *reg_off, arx_reg *regs, arx_aln *alns, uint32_t *cigars, int32_t *cand_off, arx_cand *cands);
+
 /* ---- what the reference computes per barcode between placement and the BAM records, on the candidates arx_batch_rfa left on the
  * device (needs arx_batch_rfa first; uses its barcodes, penalty and centromeres):
  *   the CIGAR walk of GetAlignments (aligner.go:1505-1570, against GetSeq gobwa.go:50-80): matches and the mismatch locations in

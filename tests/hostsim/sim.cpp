@@ -132,6 +132,7 @@ struct SimRT {
 	void arena_rewind(const std::vector<size_t> &) {}
 	void h2d(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void d2h(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
+	void d2h_async(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	uint64_t free_bytes() const { return (uint64_t)1 << 32; } // test double: tables of up to 4^12 entries
 	void d2d(void *d, const void *s, size_t b) { if (b) memcpy(d, s, b); }
 	void memset0(void *d, size_t b) { memset(d, 0, b); }

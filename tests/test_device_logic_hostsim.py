@@ -164,6 +164,30 @@ def test_text_mode_word_compare_equals_base_by_base():
         assert lib.arx_test_text_match(seed, 15000) == 8 * 15000       # negative: index of the first mismatch
 
 
+def test_detached_results_survive_the_next_run(env):
+    """arx_batch_detach / arx_batch_fetch_detached: the results of one super-batch are taken home after the handle has been reset and run
+    with the next one (what a worker with two host threads per handle does)."""
+    z, ref, o = env
+    import rfadrv
+    seqs, lens = z["reads"], z["lens"]
+    n = (len(lens) // 4) * 2
+    po = np.array([0, n // 2], dtype=np.int64)
+    b = ref.batch(seqs[:n], lens[:n]).run()
+    first = b.fetch()
+    cands = b.rfa(po, [True])
+    sizes = b.detach()
+    assert sizes["n_reads"] == n and sizes["n_regs"] == len(first["regs"]) and sizes["n_cands"] == len(cands["cands"])
+    b.reset(seqs[n:2 * n], lens[n:2 * n]).run()                     # the handle moves on
+    second = b.fetch()
+    buf = {}
+    b.fetch_detached_into(buf, sizes)
+    assert (buf["reg_off"][:n + 1] == first["reg_off"]).all() and buf["regs"][:sizes["n_regs"]].tobytes() == first["regs"].tobytes()
+    assert buf["alns"][:sizes["n_regs"]].tobytes() == first["alns"].tobytes() and (buf["cigars"][:sizes["n_cigar"]] == first["cigars"]).all()
+    assert (buf["cand_off"][:n + 1] == cands["cand_off"]).all() and buf["cands"][:sizes["n_cands"]].tobytes() == cands["cands"].tobytes()
+    assert second["regs"].tobytes() != first["regs"].tobytes()
+    b.free()
+
+
 def test_index_info(env):
     z, ref, o = env
     info = ref.index_info()
