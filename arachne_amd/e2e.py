@@ -41,14 +41,15 @@ def run(ref: api.Reference, fastq_pairs, out_prefix: str, pairs_per_batch: int =
     def worker(k, r1, r2):
         try:
             batch, buf = None, {}
-            rb = api.RecBuf(lib_path=lib_path)
+            rb = [api.RecBuf(lib_path=lib_path), api.RecBuf(lib_path=lib_path)]   # two record buffers: one is written out while the next is built
             for ps in range(warm_passes + 1):
                 gate.wait()
                 batch, buf = one_pass(k, r1, r2, batch, buf, rb, ps == warm_passes)
                 gate.wait()
             if batch is not None:
                 batch.free()
-            rb.free()
+            for x in rb:
+                x.free()
         except BaseException as e:  # noqa: BLE001 -- reported by the caller's thread
             errors.append(e)
             gate.abort()
@@ -58,6 +59,31 @@ def run(ref: api.Reference, fastq_pairs, out_prefix: str, pairs_per_batch: int =
             fd = api.Feeder(r1, r2, lib_path=lib_path)
             bam = api.BamWriter(f"{out_prefix}.{k}.bam", names, clens, extra_header="@PG\tID:arachne_amd\n", threads=bam_threads, level=level, lib_path=lib_path)
             loc = dict(pairs=0, records=0, batches=0, feeder_s=0.0, device_s=0.0, fetch_s=0.0, records_s=0.0, bam_s=0.0)
+            # the worker's BamThread (bamwriter.go:615-658): record views are compressed and written by a thread of their own while the worker
+            # goes on with the next barcode sets; a view's record buffer is reused two batches later, when its write has returned
+            import queue
+            wq = queue.Queue(maxsize=1)
+            written = [threading.Event(), threading.Event()]
+            for e_ in written:
+                e_.set()
+            werr = []
+
+            def writer():
+                while True:
+                    item = wq.get()
+                    if item is None:
+                        return
+                    slot, view = item
+                    try:
+                        t_ = time.time()
+                        bam.write_view(view)
+                        loc["bam_s"] += time.time() - t_
+                    except BaseException as e:  # noqa: BLE001
+                        werr.append(e)
+                    finally:
+                        written[slot].set()
+            wt = threading.Thread(target=writer)
+            wt.start()
             while True:
                 t0 = time.time()
                 nx = fd.next_raw(pairs_per_batch)
@@ -74,12 +100,20 @@ def run(ref: api.Reference, fastq_pairs, out_prefix: str, pairs_per_batch: int =
                 batch.fetch_into(buf)
                 post = batch.post_into(buf)
                 t3 = time.time()
-                view = rb.build(sb, buf["cand_off"], buf["cands"], buf["alns"], buf["cigars"], post, threads=rec_threads)
+                slot = loc["batches"] & 1
+                written[slot].wait()                    # the buffer's last view is on disk
+                if werr:
+                    raise werr[0]
+                view = rb[slot].build(sb, buf["cand_off"], buf["cands"], buf["alns"], buf["cigars"], post, threads=rec_threads)
                 t4 = time.time()
-                bam.write_view(view)
-                t5 = time.time()
+                written[slot].clear()
+                wq.put((slot, view))
                 loc["pairs"] += int(v["n_pairs"]); loc["records"] += int(view.n_records); loc["batches"] += 1
-                loc["feeder_s"] += t1 - t0; loc["device_s"] += t2 - t1; loc["fetch_s"] += t3 - t2; loc["records_s"] += t4 - t3; loc["bam_s"] += t5 - t4
+                loc["feeder_s"] += t1 - t0; loc["device_s"] += t2 - t1; loc["fetch_s"] += t3 - t2; loc["records_s"] += t4 - t3
+            wq.put(None)
+            wt.join()
+            if werr:
+                raise werr[0]
             t5 = time.time()
             st = bam.close()
             loc["bam_s"] += time.time() - t5

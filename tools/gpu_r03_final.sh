@@ -4,6 +4,11 @@ export TMPDIR=/tmp
 O=gpurun_out/r03z; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -n 4 $O/tests.log
 [ $rc -eq 0 ] || exit 1
+for m in mixed repeats long; do
+  timeout -k 10 300 python tools/gpu_fuzz.py 12 7100 $m > $O/fuzz_$m.log 2>&1; rc=$?; echo "fuzz $m rc=$rc: $(tail -n 1 $O/fuzz_$m.log)"
+  if grep -q HSA_STATUS_ERROR $O/fuzz_$m.log; then echo "GPU FAULT in fuzz $m"; exit 1; fi
+  [ $rc -eq 0 ] || exit 1
+done
 bash tools/gpu_profile.sh > $O/profile.log 2>&1; echo "profile rc=$?"; grep -E "sw counters|seed traffic|bench plain" $O/profile.log | cut -c1-1200
 if grep -rq "HSA_STATUS_ERROR" gpurun_out/prof/*.err; then echo "GPU FAULT in the profile passes"; exit 1; fi
 for w in grch38 vxmix chr20 alt_repeat; do
