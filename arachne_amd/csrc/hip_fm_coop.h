@@ -638,7 +638,7 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 			const int avail = pool_end - pool_next;
 			if (avail > 0) {
 				const int rank = __builtin_popcountll(idle & ((1ull << (GL * g)) - 1)); // idle groups below this one
-				if (stage == 0 && rank < avail) { t = list[pool_next + rank]; stage = 1; }
+				if (stage == 0 && in_group && rank < avail) { t = list[pool_next + rank]; stage = 1; } // (in_group: the lane that belongs to no group must not take the slot after the last idle group's)
 				const int need = __builtin_popcountll(idle);
 				pool_next += need < avail ? need : avail;
 			} else if (exhausted && __ballot(stage != 0) == 0) break;

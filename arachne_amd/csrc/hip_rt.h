@@ -221,15 +221,21 @@ struct HipRT {
 		if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
 		hipEvent_t e; ARX_HIP_CHECK(hipEventCreate(&e)); return e;
 	}
+	bool trace_launches = getenv("ARX_TRACE_LAUNCHES") != nullptr; // diagnostics: name every launch on stderr and wait for it (a fault then names its kernel)
 	struct Scope {
-		HipRT &rt; Pending p; bool on;
-		Scope(HipRT &r, const char *n, int64_t it) : rt(r), on(r.timing)
+		HipRT &rt; Pending p; bool on; const char *tn;
+		Scope(HipRT &r, const char *n, int64_t it) : rt(r), on(r.timing), tn(r.trace_launches ? n : nullptr)
 		{
+			if (tn) { fprintf(stderr, "[arx launch] %s (%lld items) ...\n", tn, (long long)it); fflush(stderr); }
 			if (!on) return;
 			p.a = rt.get_event(); p.b = rt.get_event(); p.nm = n; p.items = it;
 			(void)hipEventRecord(p.a, rt.stream);
 		}
-		~Scope() { if (on) { (void)hipEventRecord(p.b, rt.stream); rt.pending.push_back(p); } }
+		~Scope()
+		{
+			if (on) { (void)hipEventRecord(p.b, rt.stream); rt.pending.push_back(p); }
+			if (tn) { (void)hipStreamSynchronize(rt.stream); fprintf(stderr, "[arx launch] %s done\n", tn); fflush(stderr); }
+		}
 	};
 	void resolve_timers()
 	{
