@@ -151,7 +151,7 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 	// starts at once in the other buffer -- where the next start lies is known from the list itself (bwt.c:356).  Only a lane that finishes
 	// a second list before the first one has its slice parks, and a few parked lanes are enough to trigger the hand-out (grant step of
 	// persistent_lanes()).  (Parking after every extension until 48 lanes had parked left 30 of 64 lanes extending.)
-	static constexpr bool ALLOCATES = true, NEW_TASK = true;
+	static constexpr bool ALLOCATES = true, NEW_TASK = true, AUX = true;
 	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int r, len, x, head, last, cur, pend_n, pend_x, pend_buf; bool extending, awaiting, over;
 	int pend_def; uint32_t pend_code; bool want_tab; // the pending list's owed prefix (FwdLane::n_def) and its k-mer; the lane has asked for a table entry
 	__device__ FwdProg1(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), r(-1), len(0), x(0), head(-1), last(-1), cur(0), pend_n(0), pend_x(0), pend_buf(0), extending(false), awaiting(false), over(true), pend_def(0), pend_code(0), want_tab(false) {}
@@ -217,14 +217,20 @@ struct FwdProg1 { // first pass: the forward extensions of one read, start after
 };
 
 struct FwdProg2 { // re-seeding: the forward extension of one task
-	static constexpr bool ALLOCATES = true, NEW_TASK = false;
-	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int t; bool awaiting, over;
-	__device__ FwdProg2(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), t(-1), awaiting(false), over(true) {}
+	// With the per-depth tables the extension starts at the interval of its first K bases like a first-pass one (FwdLane::start_jump): a
+	// re-seeding walk (min_intv = occurrences of the SMEM + 1) ends a few bases beyond the table's depth, so the table takes 13 of its ~17
+	// dependent steps; the list prefix it owes is expanded by the grant step as in the first pass.
+	static constexpr bool ALLOCATES = true, NEW_TASK = false, AUX = true;
+	const SeedKArgs &A; Biv *list; QNibbles q; FwdLane<QNibbles> ln; int t, x; bool awaiting, over, want_tab; uint32_t tab_code;
+	__device__ FwdProg2(const SeedKArgs &a, Biv *l, QNibbles qq) : A(a), list(l), q(qq), t(-1), x(0), awaiting(false), over(true), want_tab(false), tab_code(0) {}
 	__device__ bool begin(int item)
 	{
 		t = A.t0 + item;
 		const SeedTask k = A.P.tasks[t];
-		ln.start(A.ix, A.lens[k.read], q, k.x, k.min_intv, list);
+		x = k.x;
+		uint64_t code = 0;
+		want_tab = ln.start_jump(A.ix, A.lens[k.read], q, k.x, k.min_intv, list, &code);
+		tab_code = (uint32_t)code;
 		over = false; awaiting = false;
 		return true;
 	}
@@ -232,31 +238,36 @@ struct FwdProg2 { // re-seeding: the forward extension of one task
 	{
 		*rb = 0;
 		if (over || awaiting) return false;
+		if (want_tab) { req->k = tab_code; *rc = -1; return true; } // the interval of the first K bases: one table load (consume_aux)
 		if (ln.advance(req, rc)) return true;
 		(void)slow_ok;
 		awaiting = true; // the list wants its pool slice: handed out in the wavefront's next grant step
 		return false;
 	}
-	__device__ int want() const { return awaiting ? 3 * ln.n : 0; }
+	__device__ int want() const { return awaiting ? 3 * (ln.n + ln.n_def) : 0; } // (an upper bound while a prefix is owed, as in FwdProg1)
 	__device__ bool parked() const { return awaiting; }
 	__device__ int export_off() const { return (int)(list - A.scratch); }
-	__device__ int export_def() const { return 0; } // (re-seeding extensions end within a few bases of where a k-mer table would take them: base by base)
-	__device__ uint32_t export_code() const { return 0; }
-	__device__ int export_x() const { return 0; }
-	__device__ void granted(int off, int, int)
+	__device__ int export_def() const { return ln.n_def; }
+	__device__ uint32_t export_code() const { return ln.code; }
+	__device__ int export_x() const { return x; }
+	__device__ void granted(int off, int, int n_act)
 	{
 		awaiting = false; over = true;
-		if ((int64_t)off + 3 * ln.n > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); return; } // n stays 0: the task is skipped
-		A.P.tasks[t].off = off; A.P.tasks[t].n = ln.n; // the list itself was copied to pool + off by the wavefront, persistent_lanes()
+		if ((int64_t)off + 3 * (ln.n + ln.n_def) > A.P.pool_cap) { atomicOr(A.P.err, ERR_POOL_OVERFLOW); return; } // n stays 0: the task is skipped
+		A.P.tasks[t].off = off; A.P.tasks[t].n = n_act; // the list itself (own entries + owed prefix) was written to pool + off by the wavefront, persistent_lanes()
 	}
 	__device__ void consume(const Biv &, const Biv &ok) { ln.consume(ok); }
-	__device__ void consume_aux(uint32_t, uint32_t, uint32_t, uint32_t) {}
+	__device__ void consume_aux(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+	{
+		want_tab = false;
+		ln.take_jump(A.ix, ktab_unpack((uint64_t)w1 << 32 | w0, (uint64_t)w3 << 32 | w2));
+	}
 	__device__ bool done() const { return over; }
 	__device__ void finish() {}
 };
 
 struct BwdProg { // the backward sweep of one task
-	static constexpr bool ALLOCATES = false, NEW_TASK = false;
+	static constexpr bool ALLOCATES = false, NEW_TASK = false, AUX = false;
 	const SeedKArgs &A; QNibbles q; BwdLane<QNibbles> ln; int t;
 	__device__ BwdProg(const SeedKArgs &a, Biv *, QNibbles qq) : A(a), q(qq), t(-1) { ln.finished = true; }
 	__device__ bool begin(int item)
@@ -452,7 +463,7 @@ __device__ __forceinline__ void persistent_lanes(const SeedKArgs &A, int n, int3
 			if (took && !prog.begin(item)) item = -1; // nothing to do for this item; the lane asks again next time round
 			if (item >= 0 && !have_req) have_req = prog.advance(&req, &rb, &rc, true); // an item that ends here is finished the next time round
 		}
-		if (Prog::NEW_TASK && (A.ix.klv || A.ix.isa40)) { // first pass with k-mer tables and / or text mode: a lane may ask for 16 bytes from
+		if (Prog::AUX && (A.ix.klv || A.ix.isa40)) { // forward passes with k-mer tables and / or text mode: a lane may ask for 16 bytes from
 			// somewhere (rc < 0: a table entry, a suffix-array entry, reference text; dev_fm.h aux_addr) where the others ask for an extension; that
 			// load is issued for every lane (the first Occ block for those that want none: a cached line) ahead of the Occ loads, so that one
 			// wait covers both kinds
