@@ -397,6 +397,49 @@ ARX_DEVI int text_match_chunk(const IndexView &ix, uint32_t w0, uint32_t w1, uin
 	return m;
 }
 
+// The mirror image for the backward direction (the entry-parallel backward sweeps, hip_fm_coop.h k_seed_bwd_e): q[i], q[i - 1], ... against
+// T[t], T[t - 1], ..., at most 24 bases per call.  The chunk is the 16 bytes at text_chunk_word_back(t): on the forward strand the word of t and
+// the three below it (read downwards: the byte-swapped word is that order), on the reverse strand the words of the mirrored position upwards,
+// complemented.  qw0 holds q[i] (the word i >> 3 of the read's row of 4-bit codes), qw1 .. qw3 the words below it (word 0 again below index 0).
+ARX_DEVI int64_t text_chunk_word_back(const IndexView &ix, uint64_t t)
+{
+	if ((int64_t)t < ix.l_pac) return (int64_t)(t >> 4) - 3; // (down to -3: the spare bytes in front of the packed strand)
+	return ((ix.l_pac << 1) - 1 - (int64_t)t) >> 4;
+}
+ARX_DEVI uint32_t nib_reverse(uint32_t x) { return __builtin_bswap32(((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu)); } // the eight 4-bit codes of a word in reverse order
+ARX_DEVI int text_match_back(const IndexView &ix, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint64_t t, uint32_t qw0, uint32_t qw1, uint32_t qw2, uint32_t qw3, int i, bool *more)
+{
+	uint32_t s0, s1, s2, s3;
+	int sh, avail;
+	if ((int64_t)t < ix.l_pac) {
+		const int bt = (int)(t & 15);
+		s0 = __builtin_bswap32(w3); s1 = __builtin_bswap32(w2); s2 = __builtin_bswap32(w1); s3 = __builtin_bswap32(w0);
+		sh = 2 * (15 - bt);
+		avail = (int)((uint64_t)(bt + 49) < t + 1 ? (uint64_t)(bt + 49) : t + 1);
+	} else {
+		const int64_t u = (ix.l_pac << 1) - 1 - (int64_t)t;
+		const int a0 = (int)(u & 15);
+		s0 = ~text_fwd_word(w0); s1 = ~text_fwd_word(w1); s2 = ~text_fwd_word(w2); s3 = ~text_fwd_word(w3);
+		sh = 2 * a0;
+		avail = (int)(64 - a0 < ix.l_pac - u ? 64 - a0 : ix.l_pac - u); // down to the strand boundary; the text goes on below it
+	}
+	const uint32_t z0 = text_funnel(s1, s0, sh), z1 = text_funnel(s2, s1, sh);
+	(void)s3;
+	// the read downwards from i: position 0 of the stream is q[i]
+	const uint32_t r0 = nib_reverse(qw0), r1 = nib_reverse(qw1), r2 = nib_reverse(qw2), r3 = nib_reverse(qw3);
+	const uint32_t a = nib_squeeze(r0) | nib_squeeze(r1) << 16, b = nib_squeeze(r2) | nib_squeeze(r3) << 16;
+	const uint32_t fa = nib_squeeze(r0 >> 2) | nib_squeeze(r1 >> 2) << 16, fb = nib_squeeze(r2 >> 2) | nib_squeeze(r3 >> 2) << 16;
+	const int rs = 2 * (7 - (i & 7));
+	const uint32_t y0 = text_funnel(b, a, rs), y1 = b >> rs, f0 = text_funnel(fb, fa, rs), f1 = fb >> rs;
+	const uint32_t d0 = (z0 ^ y0) | f0, d1 = ((z1 ^ y1) | f1) | 0xffff0000u; // 16 + 8 bases
+	int m = d0 ? __builtin_ctz(d0) >> 1 : 16 + (__builtin_ctz(d1) >> 1);
+	const int lim = avail < 24 ? avail : 24;
+	if (m > lim) m = lim;
+	if (m > i + 1) m = i + 1;
+	*more = m == lim && m < i + 1 && (uint64_t)m < t + 1;
+	return m;
+}
+
 template <class Q> struct FwdLane {
 	Q q; Biv *list; int len, i, min_intv, n; bool finished; Biv ik;
 	int n_def, x0; uint32_t code; // owed list prefix (0: none), the start, the code of its first klv_k bases

@@ -734,6 +734,128 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd_g(SeedKArg
 	__builtin_amdgcn_wave_barrier();
 	seed_bwd_g_body<64>(A, bins + 3 * (size_t)n, cnt + 3, cnt + 7, 2, heavy_flag);
 }
+// ---- the backward sweeps, entry-parallel (end of round 3; ARX_SEED_BWD2=3).  What bwt_smem1a's backward loop computes (bwt.c:322-348) is,
+// for every interval of the forward list on its own, how far to the left it can be extended before it holds fewer than min_intv occurrences:
+//  * an interval's fate does not depend on the others -- extending is a function of the interval and the base;
+//  * a longer match's occurrences are among a shorter one's, so the intervals give up in list order (longest first) and an interval that
+//    gives up finds every longer one gone: "no survivor precedes it" always holds, and it becomes an SMEM iff its start lies strictly left
+//    of the last SMEM's (the "contained" test; intervals that give up in the same row leave the SMEM to the longest);
+//  * a survivor that is dropped for having the size of the survivor before it (bwt.c:341) has that one's occurrences, hence its fate:
+//    it would give up in the same row and lose the same test.
+// So every list entry is an item of its own for one lane: no rows, no groups, no lanes idling beside a short list; an entry that is down to
+// ONE occurrence (first pass) goes on by comparing text (dev_fm.h text_match_back), the way the forward extensions do.  A lane walks through
+// stages: 0 idle -> 1 its item's descriptor -> 2 the list entry -> 3 extending | 4 suffix-array entry -> 5 text -> 6 the inverse's entry;
+// one wait on memory per iteration, with every load any lane needs in flight.  KBwdEFinal then applies the start test per task, in list order.
+// Results are those of the row-parallel kernel bit for bit.
+struct BwdItem { uint32_t src, dst, read, xm; }; // pool index of the list entry, of its result (the task's second list), the read, x | min_intv << 16
+
+static __global__ void __launch_bounds__(256) k_bwd_e_count(const SeedTask *tasks, int t0, int n, int32_t *cnt)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { const SeedTask k = tasks[t0 + i]; cnt[i] = k.x > 0 ? k.n : 0; } // x == 0: nothing lies before the read (k_bwd_e_expand emits the longest match)
+}
+static __global__ void __launch_bounds__(256) k_bwd_e_expand(SeedTask *tasks, Biv *pool, int t0, int n, const int32_t *off, BwdItem *items)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const SeedTask k = tasks[t0 + i];
+	if (k.n == 0) return;
+	if (k.x == 0) { pool[k.off + 2 * k.n] = pool[k.off]; tasks[t0 + i].nm = 1; return; }
+	BwdItem it; it.read = (uint32_t)k.read; it.xm = (uint32_t)k.x | (uint32_t)k.min_intv << 16;
+	for (int j = 0; j < k.n; ++j) { it.src = (uint32_t)(k.off + j); it.dst = (uint32_t)(k.off + k.n + j); items[off[i] + j] = it; }
+}
+static __global__ void __launch_bounds__(256) k_bwd_e_final(SeedTask *tasks, Biv *pool, int t0, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const SeedTask k = tasks[t0 + i];
+	if (k.n == 0 || k.x == 0) return;
+	int nm = 0, mls = 0;
+	for (int j = 0; j < k.n; ++j) { // longest match first (bwt.c:322): an interval is an SMEM iff it starts left of the last one found (bwt.c:329)
+		const Biv r = pool[k.off + k.n + j];
+		const int start = (int)(r.info >> 32);
+		if (nm == 0 || start < mls) { pool[k.off + 2 * k.n + nm] = r; ++nm; mls = start; }
+	}
+	tasks[t0 + i].nm = nm;
+}
+
+static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd_e(SeedKArgs A, const BwdItem *items, int n, int32_t *counter, int chunk)
+{
+	const int lane = threadIdx.x, rw = A.row >> 2;
+	const bool text = A.ix.sa40 && A.ix.isa40;
+	int stage = 0, item = 0, i = 0, min_intv = 1;
+	uint32_t d_src = 0, d_dst = 0, d_read = 0, d_xm = 0;
+	Biv cur = Biv();                 // info: the end of the match (the start is added when the entry is through)
+	uint64_t tpos = 0; bool moved = false;
+	int pool_next = 0, pool_end = 0; bool exhausted = false; // wave-uniform: the reserved chunk of items
+	unsigned long long n_it = 0, n_ext = 0;
+	auto finish = [&]() { Biv r = cur; r.info = (uint64_t)(uint32_t)cur.info | (uint64_t)(i + 1) << 32; A.P.pool[d_dst] = r; stage = 0; };
+	for (;;) {
+		// A. an extending lane that has run off the read is through; one whose interval holds one occurrence goes on in the text
+		if (stage == 3) {
+			if (i < 0) finish();
+			else if (text && min_intv == 1 && cur.s == 1) { stage = 4; tpos = cur.k; }
+		}
+		if (A.dbg) { ++n_it; n_ext += __builtin_popcountll(__ballot(stage >= 3)); }
+		// B. idle lanes take items
+		const unsigned long long idle = __ballot(stage == 0);
+		if (idle) {
+			if (pool_next == pool_end && !exhausted) {
+				int base = 0;
+				if (lane == 0) base = atomicAdd(counter, chunk);
+				base = __shfl(base, 0);
+				if (base >= n) { exhausted = true; pool_next = pool_end = n; }
+				else { pool_next = base; pool_end = base + chunk < n ? base + chunk : n; }
+			}
+			const int avail = pool_end - pool_next;
+			if (avail > 0) {
+				const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+				if (stage == 0 && rank < avail) { item = pool_next + rank; stage = 1; }
+				const int need = __builtin_popcountll(idle);
+				pool_next += need < avail ? need : avail;
+			} else if (exhausted && idle == ~0ull) break;
+		}
+		// C. everything this iteration needs from memory
+		__builtin_amdgcn_sched_barrier(0);
+		ExtLoad L;
+		ext_issue(A.ix, cur, 1, stage == 3, L);
+		const uint32_t *ap = stage == 1 ? (const uint32_t *)(items + item) : stage == 4 ? aux_addr(A.ix, RC_SA, tpos)
+		                   : stage == 5 ? (const uint32_t *)A.ix.pac + text_chunk_word_back(A.ix, tpos) : stage == 6 ? aux_addr(A.ix, RC_ISA, tpos) : A.ix.bwt;
+		const uint32_t x0 = ap[0], x1 = ap[1], x2 = ap[2], x3 = ap[3];
+		const bool reading = stage == 3 || stage == 5;
+		const uint32_t *qrow = A.qn + (reading ? (size_t)d_read * rw : 0);
+		const int wi = reading ? i >> 3 : 0;
+		const uint32_t q0 = qrow[wi];
+		uint32_t q1 = 0, q2 = 0, q3 = 0;
+		if (__ballot(stage == 5)) { q1 = qrow[wi > 0 ? wi - 1 : 0]; q2 = qrow[wi > 1 ? wi - 2 : 0]; q3 = qrow[wi > 2 ? wi - 3 : 0]; } // (wave-uniform)
+		Biv e = Biv();
+		if (__ballot(stage == 2)) e = A.P.pool[stage == 2 ? d_src : 0];
+		__builtin_amdgcn_sched_barrier(0);
+		// D. (the first use waits)  consume
+		if (stage == 3) {
+			const int c = (int)((q0 >> (4 * (i & 7))) & 15u);
+			if (c > 3) finish();
+			else {
+				Biv ok = ext_finish(A.ix, cur, 1, c, L);
+				if (ok.s < (uint64_t)min_intv) finish();
+				else { ok.info = cur.info; cur = ok; --i; }
+			}
+		} else if (stage == 1) { d_src = x0; d_dst = x1; d_read = x2; d_xm = x3; stage = 2; }
+		else if (stage == 2) { cur = e; i = (int)(d_xm & 0xffffu) - 1; min_intv = (int)(d_xm >> 16); stage = 3; }
+		else if (stage == 4) {
+			const uint64_t p = p40_decode(x0, x1, tpos);
+			if (p == 0) finish(); // the match lies at the start of the text: nothing extends it
+			else { tpos = p - 1; moved = false; stage = 5; }
+		} else if (stage == 5) {
+			bool more;
+			const int m = text_match_back(A.ix, x0, x1, x2, x3, tpos, q0, q1, q2, q3, i, &more);
+			i -= m; tpos -= (uint64_t)m; moved = moved || m > 0;
+			if (!more) { if (moved) { tpos += 1; stage = 6; } else finish(); } // the match now lies at tpos + 1: its row is the new k (l stays)
+		} else if (stage == 6) { cur.k = p40_decode(x0, x1, tpos); finish(); }
+	}
+	if (A.dbg && lane == 0) { atomicAdd(A.dbg, n_it); atomicAdd(A.dbg + 1, n_ext); atomicAdd(A.dbg + 3, 1ull); }
+}
+
 // task ids of [t0, t0 + n) by the group size their forward list needs: bins[0] <= 16 entries, [1] <= 21, [2] <= 32, [3] the rest; cnt[4]
 static __global__ void __launch_bounds__(256) k_bin_tasks(const SeedTask *tasks, int t0, int n, int32_t *bin0, int32_t *bin1, int32_t *bin2, int32_t *bin3, int32_t *cnt, int mid)
 {

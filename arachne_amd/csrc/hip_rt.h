@@ -193,6 +193,8 @@ struct HipRT {
 	// the row-parallel backward kernel needs 94 VGPRs: five wavefronts per SIMD fit, not only the four its launch bound asks for, so its grid is
 	// 20 workgroups per CU (4.81 -> 4.62 ms alone; 24 and more lose again, and a build that forces six per SIMD spills: 7.2 ms)
 	int seed_bwd_mid = getenv("ARX_SEED_BWD_MID") ? atoi(getenv("ARX_SEED_BWD_MID")) : 21; // longest list of the 21-lane bin of the backward sweeps (16: none)
+	int seed_bwd_e_bpc = getenv("ARX_SEED_BWD_E_BPC") ? atoi(getenv("ARX_SEED_BWD_E_BPC")) : 32; // its resident workgroups per CU (62 VGPRs: eight wavefronts per SIMD fit)
+	int seed_bwd_e_chunk = getenv("ARX_SEED_BWD_E_CHUNK") ? atoi(getenv("ARX_SEED_BWD_E_CHUNK")) : 256; // list entries a wavefront reserves per atomic (entry-parallel sweeps)
 	bool text_bwd = !(getenv("ARX_TEXT_BWD") && atoi(getenv("ARX_TEXT_BWD")) == 0);
 	int seed_bwd_bpc = getenv("ARX_SEED_BWD_BPC") ? atoi(getenv("ARX_SEED_BWD_BPC")) : 20;
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
@@ -423,6 +425,23 @@ struct HipRT {
 		memset0(heavy + n, 4);
 		SeedKArgs A{f.ix, f.bases, f.base_off, f.lens, f.P, nullptr, 0, nullptr, f.t0, heavy, heavy + n, seed_bwd_budget, seed_row, seed_qn, 0, seed_dbg()};
 		if (!text_bwd) A.ix.isa40 = nullptr; // ARX_TEXT_BWD=0: every sweep walked to its end (k_seed_bwd_g hands nothing to KSeedBwdTail)
+		if (seed_bwd2 == 3 && seed_row <= 132) { // entry-parallel sweeps (k_seed_bwd_e): one lane per list entry
+			int32_t *ecnt = alloc<int32_t>((size_t)n + 2), *eoff = alloc<int32_t>((size_t)n + 2);
+			Scope sc(*this, nm, n);
+			hipLaunchKernelGGL(k_bwd_e_count, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.t0, n, ecnt);
+			const int64_t total = exclusive_scan(ecnt, eoff, n); // (waits for the stream)
+			BwdItem *items = alloc<BwdItem>((size_t)total + 4);
+			hipLaunchKernelGGL(k_bwd_e_expand, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.P.pool, f.t0, n, eoff, items);
+			if (total > 0) {
+				memset0(counter, 4);
+				int64_t blocks = (total + 63) / 64; if (blocks > (int64_t)n_cu * seed_bwd_e_bpc) blocks = (int64_t)n_cu * seed_bwd_e_bpc;
+				hipLaunchKernelGGL(k_seed_bwd_e, dim3((unsigned)blocks), dim3(64), 0, stream, A, items, (int)total, counter, seed_bwd_e_chunk);
+				hipLaunchKernelGGL(k_bwd_e_final, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.P.pool, f.t0, n);
+			}
+			ARX_HIP_CHECK(hipGetLastError());
+			seed_dbg_report(nm, (int)total);
+			return;
+		}
 		if (seed_bwd2 == 2 && seed_row <= 132) { // row-parallel sweeps (k_seed_bwd_g<GL>): one task per 16/32/64-lane group, lists in registers
 			uint8_t *flag = alloc<uint8_t>((size_t)n + 8);
 			int32_t *bins = alloc<int32_t>(4 * (size_t)n + 8), *cnt = alloc<int32_t>(8); // cnt[0..3]: bin sizes, cnt[4..7]: the bins' item counters

@@ -66,10 +66,44 @@ struct KSeedFwd1 { // first pass, forward halves: the starts of a read chain thr
 
 struct KSeedBwd { // the backward sweep of task t0 + item
 	IndexView ix; const uint8_t *bases; const int32_t *base_off, *lens; SeedPools P; int t0;
+	bool by_entry = false; // the entry-by-entry form of the sweep (what hip_fm_coop.h k_seed_bwd_e + k_bwd_e_final compute): the host test double's check of its claims
+	ARX_DEV void entries(const SeedTask &t, int item) const
+	{
+		const QBytes q{bases + base_off[t.read]};
+		Biv *list = P.pool + t.off, *res = list + t.n, *mem = res + t.n;
+		if (t.x == 0) { mem[0] = list[0]; P.tasks[t0 + item].nm = 1; return; }
+		for (int j = 0; j < t.n; ++j) { // every interval on its own: how far to the left before it holds fewer than min_intv occurrences
+			Biv cur = list[j];
+			int i = t.x - 1;
+			while (i >= 0 && q.at(i) <= 3) {
+				if (ix.sa40 && ix.isa40 && t.min_intv == 1 && cur.s == 1) { // one occurrence left: the text decides (bwd_text_tail's comparison)
+					const uint64_t p = p40_load(ix.sa40, cur.k);
+					int m = 0;
+					while (i - m >= 0 && (uint64_t)m < p && q.at(i - m) <= 3 && q.at(i - m) == ref_base(ix, (int64_t)(p - 1 - (uint64_t)m))) ++m;
+					if (m) cur.k = p40_load(ix.isa40, p - (uint64_t)m);
+					i -= m;
+					break;
+				}
+				const Biv ok = extend1(ix, cur, 1, q.at(i));
+				if (ok.s < (uint64_t)t.min_intv) break;
+				const uint64_t info = cur.info;
+				cur = ok; cur.info = info; --i;
+			}
+			cur.info = (uint64_t)(uint32_t)cur.info | (uint64_t)(i + 1) << 32;
+			res[j] = cur;
+		}
+		int nm = 0, mls = 0;
+		for (int j = 0; j < t.n; ++j) { // longest first: an SMEM iff it starts left of the last one found
+			const int start = (int)(res[j].info >> 32);
+			if (nm == 0 || start < mls) { mem[nm++] = res[j]; mls = start; }
+		}
+		P.tasks[t0 + item].nm = nm;
+	}
 	ARX_DEV void operator()(int item, int) const
 	{
 		SeedTask t = P.tasks[t0 + item];
 		if (t.n == 0) return;
+		if (by_entry) { entries(t, item); return; }
 		BwdLane<QBytes> ln;
 		ln.start(QBytes{bases + base_off[t.read]}, t, P.pool);
 		ln.use_text(ix);
@@ -608,6 +642,7 @@ public:
 				}
 			}
 			KSeedBwd kb{ix, b.bases, b.base_off, b.lens, P, 0};
+			kb.by_entry = getenv("ARX_SEED_BWD_ENTRY") != nullptr; // (only the one-thread form looks at it: the host test double, ARX_SW_SIMPLE)
 			rt.run_seed_bwd("seed_bwd", n1, kb, w.counter);
 			KSeedGather1 kg1{b.bases, b.base_off, P, first1, w.intv, w.n_intv, first2, g0};
 			rt.launch_wide("seed_gather", Rg, kg1);

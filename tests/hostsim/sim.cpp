@@ -272,5 +272,52 @@ extern "C" long arx_test_text_match(unsigned seed, int iters)
 	return cases;
 }
 
+// test entry: the backward comparison of text mode (dev_fm.h text_match_back: the entry-parallel backward sweeps) against the text itself
+extern "C" long arx_test_text_match_back(unsigned seed, int iters)
+{
+	using namespace arx;
+	uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 7);
+	auto rnd = [&](int m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (int)(x % (uint64_t)m); };
+	long cases = 0;
+	for (int it = 0; it < iters; ++it) {
+		const int64_t l_pac = 40 + rnd(it % 5 == 0 ? 60 : 700);
+		std::vector<uint8_t> store((size_t)(l_pac / 4 + 1 + 16 + 64), 0);
+		uint8_t *pac = store.data() + 16;
+		for (int64_t p = 0; p < l_pac; ++p) pac[p >> 2] |= (uint8_t)(rnd(4) << ((~p & 3) << 1));
+		IndexView ix = IndexView();
+		ix.pac = pac; ix.l_pac = l_pac; ix.seq_len = (uint64_t)(2 * l_pac);
+		for (int rep = 0; rep < 8; ++rep) {
+			const int len = 20 + rnd(236), i = rnd(len);
+			const uint64_t t = (uint64_t)rnd((int)(2 * l_pac));
+			std::vector<uint8_t> q((size_t)len + 8, 4);
+			const int m_want = rnd(3) == 0 ? rnd(6) : rnd(60);          // equal bases from (i, t) downwards, then a difference
+			for (int j = 0; j < len; ++j) q[(size_t)j] = (uint8_t)rnd(4);
+			for (int j = 0; i - j >= 0 && (int64_t)t - j >= 0 && j <= m_want; ++j) {
+				const int b = ref_base(ix, (int64_t)t - j);
+				q[(size_t)(i - j)] = (uint8_t)(j < m_want ? b : (b + 1 + rnd(3)) & 3);
+			}
+			if (rnd(6) == 0) q[(size_t)rnd(i + 1)] = 4;
+			std::vector<uint32_t> rowbuf((size_t)(len + 16) / 8 + 4, 0x44444444u);
+			uint8_t *row = (uint8_t *)rowbuf.data();
+			for (int j = 0; j < len; ++j) row[j >> 1] = (uint8_t)((row[j >> 1] & ~(15 << ((j & 1) << 2))) | q[(size_t)j] << ((j & 1) << 2));
+			// walk as the kernel does: chunk after chunk until the comparison stops
+			int ii = i; uint64_t tt = t; int total = 0; bool more = true;
+			while (more) {
+				const uint32_t *w = (const uint32_t *)ix.pac + text_chunk_word_back(ix, tt);
+				const int wi = ii >> 3;
+				auto qword = [&](int k) { return rowbuf[(size_t)(wi - k > 0 ? wi - k : 0)]; };
+				const int m = text_match_back(ix, w[0], w[1], w[2], w[3], tt, qword(0), qword(1), qword(2), qword(3), ii, &more);
+				total += m; ii -= m; tt -= (uint64_t)m;
+				if (more && (ii < 0 || m == 0)) return -(cases + 1);   // `more` promises progress and room
+			}
+			int truth = 0;
+			while (i - truth >= 0 && (int64_t)t - truth >= 0 && q[(size_t)(i - truth)] < 4 && q[(size_t)(i - truth)] == ref_base(ix, (int64_t)t - truth)) ++truth;
+			++cases;
+			if (total != truth) return -cases;
+		}
+	}
+	return cases;
+}
+
 // the wavefront routines exist on the GPU only (include/arachne_amd.h): nothing to test here
 extern "C" int arx_selftest_wave_sort(int32_t, int32_t, int64_t, int64_t *n_bad) { if (n_bad) *n_bad = 0; return ARX_E_DEVICE; }

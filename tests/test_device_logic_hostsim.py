@@ -188,6 +188,38 @@ def test_detached_results_survive_the_next_run(env):
     b.free()
 
 
+@pytest.mark.parametrize("text", ["1", "0"])
+def test_backward_sweeps_entry_by_entry(monkeypatch, text):
+    """What the entry-parallel backward kernel (k_seed_bwd_e) rests on: every interval of a forward list can be extended to the left on its
+    own, and the SMEMs are those whose start lies left of the last one's, in list order -- on the nasty workload (repeats, ties, ambiguous
+    bases, ALT contigs), with and without text mode, interval for interval against the restatement."""
+    import oradrv
+    monkeypatch.setenv("ARX_SEED_BWD_ENTRY", "1")
+    monkeypatch.setenv("ARX_TEXT_INDEX", text)
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    z = np.load(GOLD)
+    prefix = workloads.unpack_index(z, tempfile.mkdtemp(prefix="arx_sim_e_"))
+    ref = api.Reference(prefix, lib_path=SIM)
+    o = oradrv.Oracle(prefix)
+    seqs, lens = z["reads"], z["lens"]
+    b = ref.batch(seqs, lens).run()
+    parity.check_intervals(b, o, seqs, lens)
+    parity.check_final(b.fetch(), o.batch(seqs, lens, n_threads=4))
+    b.free()
+    ref.close()
+    o.close()
+    g = workloads.nasty_genome(31, contig_lens=(90000, 40000, 15000), alt_contigs=2)
+    rs = workloads.nasty_reads(31, g, n_barcodes=3, pairs_per_barcode=250)
+    d = tempfile.mkdtemp(prefix="arx_sim_e2_"); fa = os.path.join(d, "g.fa")
+    g.write_fasta(fa); g.write_alt(fa + ".alt")
+    api.index_build(fa, fa, lib_path=SIM)
+    ref = api.Reference(fa, lib_path=SIM)
+    o = oradrv.Oracle(fa)
+    b = ref.batch(rs.seqs, rs.lens).run()
+    parity.check_intervals(b, o, rs.seqs, rs.lens)
+    b.free(); ref.close(); o.close()
+
+
 def test_index_info(env):
     z, ref, o = env
     info = ref.index_info()
