@@ -197,9 +197,154 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 	return r;
 }
 
+// The same pass on PACKED 16-bit pairs (end of round 3): a register holds two cells, the group is 32 virtual lanes -- lane l's low halves are
+// segment l of the query, its high halves segment l + 16, each segment S2 = SL / 2 positions long -- and every add / subtract / maximum of
+// the row is one v_pk_*_i16 for both.  The recurrence within a segment is the serial one of the unpacked form, the two halves of a register
+// never meet except where a segment hands H or F to the next one: there the packed value moves one lane up and lane 0's high half takes lane
+// 15's low half (one row rotation and a select).  The score lookup is one v_perm_b32 per pair: the row's five scores as bytes, the pair's two
+// query codes as the selector.  Values stay below 255 + 5 (reads under 250 bases), far inside 16 bits; the results are the unpacked form's
+// (the DP is the same function of the two sequences however its cells are laid out; the lazy-F loop runs to the same fixed point).
+typedef short arx_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, (arx_s2)(__builtin_bit_cast(arx_s2, a) + __builtin_bit_cast(arx_s2, b))); }
+__device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (arx_s2)(__builtin_bit_cast(arx_s2, a) - __builtin_bit_cast(arx_s2, b))); }
+__device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(arx_s2, a), __builtin_bit_cast(arx_s2, b))); }
+__device__ __forceinline__ int pk_rot_up(int v, int l) // every half to the next segment: lane l <- lane l - 1; lane 0: low half 0 (no segment before the first), high half <- lane 15's low half
+{
+	const int r = dpp_rowz<DPP_ROW_ROR + 1>(v);
+	return l == 0 ? (int)((uint32_t)r << 16) : r;
+}
+__device__ __forceinline__ int pk_g16_max(int v) // both halves reduced over the group, then against each other: the row maximum in every lane
+{
+	int t;
+	t = dpp_rowz<DPP_ROW_ROR + 8>(v); v = pk_max(v, t);
+	t = dpp_rowz<DPP_ROW_ROR + 4>(v); v = pk_max(v, t);
+	t = dpp_rowz<DPP_ROW_ROR + 2>(v); v = pk_max(v, t);
+	t = dpp_rowz<DPP_ROW_ROR + 1>(v); v = pk_max(v, t);
+	const int lo = (int)(short)(v & 0xffff), hi = v >> 16;
+	return lo > hi ? lo : hi;
+}
+template <int S2, bool FULL>
+__device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
+{
+	const int l = __lane_id() & 15;
+	const int slen = FULL ? S2 : (qlen + 31) >> 5;
+	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000, endsc = (xtra & KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
+	const int C4 = 0x00040004, C7 = 0x00070007, C1 = 0x00010001;
+	int H0[S2], H1[S2], E[S2], HM[S2];
+	uint32_t QS[S2]; // v_perm selector of the pair: byte 0 <- score byte of the low half's query code, byte 2 <- the high half's, bytes 1 and 3 <- 0
+#pragma unroll
+	for (int j = 0; j < S2; ++j) {
+		const int ka = j + l * slen, kb = j + (l + 16) * slen;
+		H0[j] = H1[j] = E[j] = HM[j] = 0;
+		const uint32_t qa = (j < slen && ka < qlen) ? (uint32_t)sq.q(ka) : 5u, qb = (j < slen && kb < qlen) ? (uint32_t)sq.q(kb) : 5u;
+		QS[j] = qa | 0x0c00u | qb << 16 | 0x0c000000u;
+	}
+	int gmax = 0, te = -1, hlast = 0, rows = 0;
+	auto row = [&](const int (&Hin)[S2], int (&Hout)[S2], int i) __attribute__((always_inline)) -> bool {
+		const int tb = sq.t(i);
+		// the row's scores + 4 as bytes: query codes 0..3 in the low word (match 5, mismatch 0; a target N: 3 everywhere), N -> 3 and padding -> 4 in the high word
+		const uint32_t Wlo = tb > 3 ? 0x03030303u : 5u << (8 * tb), Whi = 0x0403u;
+		int h = pk_rot_up(hlast, l), f = 0, mx = 0;
+#pragma unroll
+		for (int j = 0; j < S2; ++j) {
+			const bool valid = j < slen;
+			const int s = (int)__builtin_amdgcn_perm(Whi, Wlo, QS[j]);
+			const int hd = pk_sub(pk_add(h, s), C4);
+			const int hh = pk_max(pk_max(hd, E[j]), f);
+			Hout[j] = hh;
+			const int h7 = pk_sub(hh, C7);
+			E[j] = pk_max(pk_max(pk_sub(E[j], C1), h7), 0);
+			const int fn = pk_max(pk_max(pk_sub(f, C1), h7), 0);
+			f = valid ? fn : f;
+			mx = pk_max(mx, valid ? hh : 0);
+			h = Hin[j];
+		}
+		{ // lazy-F (ksw.c:177-189): first step straight-line, the general loop behind a branch
+			bool stop;
+			f = pk_rot_up(f, l);
+			{
+				const int hh = pk_max(Hout[0], f);
+				Hout[0] = hh;
+				const int t7 = pk_max(pk_sub(hh, C7), 0);
+				f = pk_max(pk_sub(f, C1), 0);
+				stop = g16_all(pk_max(f, t7) == t7); // no half with f > t7
+			}
+			if (!stop) {
+				for (int k2 = 0; k2 < 32 && !stop; ++k2) {
+					if (k2) f = pk_rot_up(f, l);
+#pragma unroll
+					for (int j = 0; j < S2; ++j) {
+						if (j < slen && !stop && (k2 || j)) {
+							const int hh = pk_max(Hout[j], f);
+							Hout[j] = hh;
+							const int t7 = pk_max(pk_sub(hh, C7), 0);
+							f = pk_max(pk_sub(f, C1), 0);
+							if (g16_all(pk_max(f, t7) == t7)) stop = true;
+						}
+					}
+				}
+				mx = 0;
+#pragma unroll
+				for (int j = 0; j < S2; ++j) mx = pk_max(mx, j < slen ? Hout[j] : 0);
+			}
+		}
+		const int imax = pk_g16_max(mx);
+		if (minsc < 0x10000 && l == 0) rowmax[i] = (uint8_t)imax;
+		++rows;
+		bool brk = false;
+		if (imax > gmax) {
+			gmax = imax; te = i;
+#pragma unroll
+			for (int j = 0; j < S2; ++j) HM[j] = Hout[j];
+			if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
+		}
+#pragma unroll
+		for (int j = 0; j < S2; ++j) if (j == slen - 1) hlast = Hout[j];
+		return brk;
+	};
+	for (int i = 0; i < tlen; i += 2) {
+		if (row(H0, H1, i)) break;
+		if (i + 1 < tlen && row(H1, H0, i + 1)) break;
+	}
+	U8Res r;
+	r.score = gmax + 4 < 255 ? gmax : 255; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1; r.tb = -1; r.qb = -1;
+	if (r.score != 255) {
+		int bv = -1, bq = 0x7fffffff; // this lane's best saved value and the smallest query position holding it
+#pragma unroll
+		for (int j = 0; j < S2; ++j) {
+			if (j < slen) {
+				const int va = (int)(short)(HM[j] & 0xffff), vb = HM[j] >> 16, qa = j + l * slen, qb = j + (l + 16) * slen;
+				if (va > bv || (va == bv && qa < bq)) { bv = va; bq = qa; }
+				if (vb > bv || (vb == bv && qb < bq)) { bv = vb; bq = qb; }
+			}
+		}
+		const int vmax = g16_max(bv);
+		r.qe = g16_min(bv == vmax ? bq : 0x7fffffff);
+		if (minsc < 0x10000 && l == 0) { // replay of the b[] list (ksw.c:192-200,218-226), see u8_pass() in dev_sw.h
+			const int d = r.score, low = te - d, high = te + d;
+			int bi = -1, bs = -1;
+			for (int i = 0; i < rows; ++i) {
+				int im = rowmax[i];
+				if (im < minsc) continue;
+				if (bi < 0 || bi + 1 != i) {
+					if (bi >= 0 && (bi < low || bi > high) && bs > r.score2) { r.score2 = bs; r.te2 = bi; }
+					bi = i; bs = im;
+				} else if (bs < im) { bi = i; bs = im; }
+			}
+			if (bi >= 0 && (bi < low || bi > high) && bs > r.score2) { r.score2 = bs; r.te2 = bi; }
+		}
+	}
+	return r;
+}
+
+#ifndef ARX_SW_PACKED
+#define ARX_SW_PACKED 1 // 0: the unpacked pass for the 8-bit element size too (A/B)
+#endif
 template <int SL>
 __device__ __forceinline__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
 {
+	if (ARX_SW_PACKED && (SL & 1) == 0)
+		return ((qlen + 31) >> 5) == SL / 2 ? sw_u8_pass_p16_impl<SL / 2, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_p16_impl<SL / 2, false>(sq, qlen, tlen, xtra, rowmax);
 	return ((qlen + 15) >> 4) == SL ? sw_u8_pass_g16_impl<SL, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_g16_impl<SL, false>(sq, qlen, tlen, xtra, rowmax);
 }
 template <int SL>
