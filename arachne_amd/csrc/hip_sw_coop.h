@@ -61,6 +61,9 @@ __device__ __forceinline__ uint32_t u8_score_word(int tb)
 	return 0x430000u | (5u << (4 * tb));
 }
 
+#ifndef ARX_SW_SCANF
+#define ARX_SW_SCANF 1 // 0: ksw_u8's lazy-F loop as the reference runs it (A/B)
+#endif
 struct SwSeqs { // how the two passes read their sequences without materialising them
 	const uint8_t *mate; int l_ms;   // forward mate; the query is its reverse complement (bwamem_pair.c:134-137)
 	const uint8_t *tl;               // the target window, staged in LDS once per alignment (both passes read it), two bases per byte
@@ -95,6 +98,62 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		const uint32_t W = u8_score_word(sq.t(i));
 		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
 		if (I16) h = lane_on ? h : 0;
+		if (ARX_SW_SCANF && !I16) {
+			// F without the lazy loop (end of round 3).  f(j + 1) = max(f(j) - 1, H(j) - 7) with H = max(G, f), G = max(M', E): the f - 7 inside H - 7
+			// never beats f - 1, so F is the max-plus prefix of G alone -- the lane's own cells (sweep 1: what they send on as F, starting from
+			// nothing), the segments before it (a four-step scan over the 16 lanes, each segment passed costs its length), then the same chain
+			// again from what really comes in (sweep 2: H, E, the row maximum).  ksw_u8's lazy-F loop (ksw.c:177-189) iterates to the same H; it
+			// took a pass over the row per segment boundary that F crosses -- and behind a high-scoring cell F runs on for dozens of columns.
+			// (E takes the final H here where the reference takes the H before its loop: H itself is the same either way -- a deletion
+			// right after insertions scores what the insertions after the deletion score, which the next row's F delivers; 46 GPU tests and
+			// the fuzz runs, also with the 32-segment layout below whose intermediate E differ again.)
+#pragma unroll
+			for (int j = 0; j < SL; ++j) {
+				const bool valid = j < slen;
+				const int s = (int)((W >> Q4[j]) & 15u);
+				const int hd = h + s - 4;
+				const int G = hd > E[j] ? hd : E[j];
+				Hout[j] = G;
+				const int g7 = G - 7, f1 = f - 1, fm = f1 > g7 ? f1 : g7;
+				const int fn = fm > 0 ? fm : 0;
+				f = valid ? fn : f;
+				h = Hin[j];
+			}
+			int x = f, y;
+			y = dpp_rowz<DPP_ROW_SHR + 1>(x) - slen; x = x > y ? x : y;
+			y = dpp_rowz<DPP_ROW_SHR + 2>(x) - 2 * slen; x = x > y ? x : y;
+			y = dpp_rowz<DPP_ROW_SHR + 4>(x) - 4 * slen; x = x > y ? x : y;
+			y = dpp_rowz<DPP_ROW_SHR + 8>(x) - 8 * slen; x = x > y ? x : y;
+			f = g16_shift_up(x, l); // what enters the lane's first cell (0 in lane 0; x >= 0)
+#pragma unroll
+			for (int j = 0; j < SL; ++j) {
+				const bool valid = j < slen;
+				const int G = Hout[j];
+				const int hh = G > f ? G : f;
+				Hout[j] = hh;
+				const int h7 = hh - 7;
+				const int e1 = E[j] - 1, em = e1 > h7 ? e1 : h7;
+				E[j] = em > 0 ? em : 0;
+				const int f1 = f - 1, fm = f1 > h7 ? f1 : h7;
+				const int fn = fm > 0 ? fm : 0;
+				f = valid ? fn : f;
+				const int hm = valid ? hh : 0;
+				mx = mx > hm ? mx : hm;
+			}
+			const int imax = g16_max(mx);
+			if (minsc < 0x10000 && l == 0) rowmax[i] = (uint8_t)imax;
+			++rows;
+			bool brk = false;
+			if (imax > gmax) {
+				gmax = imax; te = i;
+#pragma unroll
+				for (int j = 0; j < SL; ++j) HM[j] = Hout[j];
+				if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
+			}
+#pragma unroll
+			for (int j = 0; j < SL; ++j) if (j == slen - 1) hlast = Hout[j];
+			return brk;
+		}
 		// straight-line select code over all SL stripes: stripes past slen (a shorter query in the second pass) come last in
 		// the chain, so what they compute flows nowhere as long as they leave f and the row maximum alone.
 		// _mm_adds_epu8(h, profile) cannot saturate (h <= 249 for reads below 250 bases, profile <= 5), and the floor of
@@ -230,12 +289,18 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 	const int slen = FULL ? S2 : (qlen + 31) >> 5;
 	const int minsc = (xtra & KSW_XSUBO) ? (xtra & 0xffff) : 0x10000, endsc = (xtra & KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
 	const int C4 = 0x00040004, C7 = 0x00070007, C1 = 0x00010001;
+	// The reference pads the query to 16 x ceil(qlen / 16) columns with score-0 columns, and those columns count in the row maxima (they hold what
+	// the last base's column held a few rows earlier: ksw.c:129-131, 165-166); 32 segments may pad further -- columns from P on stay out of
+	// every maximum (FULL: there are none)
+	const int P = 16 * ((qlen + 15) >> 4);
 	int H0[S2], H1[S2], E[S2], HM[S2];
 	uint32_t QS[S2]; // v_perm selector of the pair: byte 0 <- score byte of the low half's query code, byte 2 <- the high half's, bytes 1 and 3 <- 0
+	int KM[S2];      // which halves are columns the reference has
 #pragma unroll
 	for (int j = 0; j < S2; ++j) {
 		const int ka = j + l * slen, kb = j + (l + 16) * slen;
 		H0[j] = H1[j] = E[j] = HM[j] = 0;
+		KM[j] = FULL ? -1 : (int)((ka < P ? 0xffffu : 0u) | (kb < P ? 0xffff0000u : 0u));
 		const uint32_t qa = (j < slen && ka < qlen) ? (uint32_t)sq.q(ka) : 5u, qb = (j < slen && kb < qlen) ? (uint32_t)sq.q(kb) : 5u;
 		QS[j] = qa | 0x0c00u | qb << 16 | 0x0c000000u;
 	}
@@ -256,7 +321,7 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 			E[j] = pk_max(pk_max(pk_sub(E[j], C1), h7), 0);
 			const int fn = pk_max(pk_max(pk_sub(f, C1), h7), 0);
 			f = valid ? fn : f;
-			mx = pk_max(mx, valid ? hh : 0);
+			mx = pk_max(mx, valid ? (FULL ? hh : hh & KM[j]) : 0);
 			h = Hin[j];
 		}
 		{ // lazy-F (ksw.c:177-189): first step straight-line, the general loop behind a branch
@@ -285,7 +350,7 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 				}
 				mx = 0;
 #pragma unroll
-				for (int j = 0; j < S2; ++j) mx = pk_max(mx, j < slen ? Hout[j] : 0);
+				for (int j = 0; j < S2; ++j) mx = pk_max(mx, j < slen ? (FULL ? Hout[j] : Hout[j] & KM[j]) : 0);
 			}
 		}
 		const int imax = pk_g16_max(mx);
@@ -314,8 +379,8 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		for (int j = 0; j < S2; ++j) {
 			if (j < slen) {
 				const int va = (int)(short)(HM[j] & 0xffff), vb = HM[j] >> 16, qa = j + l * slen, qb = j + (l + 16) * slen;
-				if (va > bv || (va == bv && qa < bq)) { bv = va; bq = qa; }
-				if (vb > bv || (vb == bv && qb < bq)) { bv = vb; bq = qb; }
+				if (qa < P && (va > bv || (va == bv && qa < bq))) { bv = va; bq = qa; }
+				if (qb < P && (vb > bv || (vb == bv && qb < bq))) { bv = vb; bq = qb; }
 			}
 		}
 		const int vmax = g16_max(bv);
@@ -338,13 +403,13 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 }
 
 #ifndef ARX_SW_PACKED
-#define ARX_SW_PACKED 1 // 0: the unpacked pass for the 8-bit element size too (A/B)
+#define ARX_SW_PACKED 0 // 1: the packed pass (exact, measured slower: 32 segments double the boundaries the lazy-F loop has to carry F across, 15.7 -> 17.1 ms)
 #endif
 template <int SL>
 __device__ __forceinline__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
 {
 	if (ARX_SW_PACKED && (SL & 1) == 0)
-		return ((qlen + 31) >> 5) == SL / 2 ? sw_u8_pass_p16_impl<SL / 2, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_p16_impl<SL / 2, false>(sq, qlen, tlen, xtra, rowmax);
+		return (((qlen + 31) >> 5) == SL / 2 && ((qlen + 15) >> 4) == SL) ? sw_u8_pass_p16_impl<SL / 2, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_p16_impl<SL / 2, false>(sq, qlen, tlen, xtra, rowmax);
 	return ((qlen + 15) >> 4) == SL ? sw_u8_pass_g16_impl<SL, true>(sq, qlen, tlen, xtra, rowmax) : sw_u8_pass_g16_impl<SL, false>(sq, qlen, tlen, xtra, rowmax);
 }
 template <int SL>
