@@ -117,7 +117,10 @@ ARX_DEVI int sat_sub8(int a, int b) { return a > b ? a - b : 0; }
 // of 250 bases and more, bwamem_pair.c:150): EIGHT stripes instead of sixteen, no bias, no 255 ceiling.  Everything else is the same
 // arithmetic -- adds_epi16(h, s) followed by the maxima with e, f >= 0 is max(h + s, 0) like the biased byte form, the gap states use the
 // same unsigned saturating subtractions -- and for reads of up to 255 bases every value still fits the byte fields of the row word.
-ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax, bool i16 = false)
+// exact_f = true (tests): the row's F by the plain recurrence over the query positions in their order -- what hip_sw_coop.h's scan computes --
+// instead of the striped main pass + lazy loop, and E from the final H: the H values, and with them every result, are the same (the host test
+// double checks that against the restatement on gapped, low-complexity and random pairs: tests/test_sw_prefilter.py).
+ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax, bool i16 = false, bool exact_f = false)
 {
 	const int shift = 4, qmax = 1; // ksw_qinit: shift = 256 - (uint8_t)min(mat) = 4, max = 1
 	const int oe_del = OPT_O_DEL + OPT_E_DEL, e_del = OPT_E_DEL, oe_ins = OPT_O_INS + OPT_E_INS, e_ins = OPT_E_INS;
@@ -131,6 +134,23 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 		const int sh_prev = cur * 8, sh_new = (cur ^ 1) * 8;
 		int imax = 0;
 		int fl[16]; // F carried across the lazy loop, one per stripe
+		if (exact_f) {
+			int f = 0, h = 0; // H(i-1, k-1) for k = 0: nothing
+			for (int k = 0; k < n16; ++k) {
+				const int ll = k / slen, jj = k % slen;
+				uint32_t wd = row[(jj * NS + ll) * stride];
+				int e = (wd >> 16) & 0xff, tt;
+				const int sc = (k >= qlen ? 0 : sc_mat(tb, q[k])) + shift;
+				int hh = i16 ? h + sc - shift : sat_sub8(sat_add8(h, sc), shift);
+				hh = hh > e ? hh : e;
+				hh = hh > f ? hh : f;
+				imax = imax > hh ? imax : hh;
+				h = (wd >> sh_prev) & 0xff;
+				e = sat_sub8(e, e_del); tt = sat_sub8(hh, oe_del); e = e > tt ? e : tt;
+				f = sat_sub8(f, e_ins); tt = sat_sub8(hh, oe_ins); f = f > tt ? f : tt;
+				row[(jj * NS + ll) * stride] = (wd & ~(0xffu << sh_new) & ~(0xffu << 16)) | (uint32_t)hh << sh_new | (uint32_t)e << 16;
+			}
+		} else {
 		// main pass: each stripe is an independent chain over its slen consecutive query positions
 		for (l = 0; l < NS; ++l) {
 			int f = 0, mx = 0;
@@ -172,6 +192,7 @@ ARX_DEV U8Res u8_pass(const PrefixRevView &q, int qlen, const PrefixRevView &tg,
 					if (all) { done = true; break; }
 				}
 			}
+		}
 		}
 		rowmax[i] = (uint8_t)imax; ++rows;
 		if (imax > gmax) {
@@ -245,14 +266,14 @@ ARX_DEVI bool sw_prefilter_serial(const uint8_t *q, int qlen, const uint8_t *t, 
 #endif
 
 // ksw_align2 (ksw.c:343-365) with XBYTE: forward pass, then a pass over the reversed prefixes to find the start
-ARX_DEV U8Res u8_align(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax)
+ARX_DEV U8Res u8_align(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int xtra, uint32_t *row, int stride, uint8_t *rowmax, bool exact_f = false)
 {
 	PrefixRevView q{query, 0}, t{target, 0};
 	const bool i16 = !(xtra & KSW_XBYTE); // ksw_align2's choice of element size (ksw.c:350-353); the second pass keeps it
-	U8Res r = u8_pass(q, qlen, t, tlen, xtra, row, stride, rowmax, i16);
+	U8Res r = u8_pass(q, qlen, t, tlen, xtra, row, stride, rowmax, i16, exact_f);
 	if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
 	PrefixRevView q2{query, r.qe + 1}, t2{target, r.te + 1};
-	U8Res rr = u8_pass(q2, r.qe + 1, t2, tlen, KSW_XSTOP | r.score, row, stride, rowmax, i16);
+	U8Res rr = u8_pass(q2, r.qe + 1, t2, tlen, KSW_XSTOP | r.score, row, stride, rowmax, i16, exact_f);
 	if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
 	return r;
 }

@@ -180,6 +180,16 @@ struct SimRT {
 #include "../../arachne_amd/csrc/api_impl.h"
 ARX_DEFINE_C_API(arx::SimRT)
 
+// test entry: ksw_align2's two passes with the row's F by the plain recurrence (dev_sw.h u8_pass, exact_f: what the rescue kernel's scan
+// computes) -- tests/test_sw_prefilter.py compares it with the restatement's striped pass + lazy-F loop
+extern "C" void arx_test_sw_exact_f(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int xtra, int exact_f, int32_t *out)
+{
+	std::vector<uint32_t> row((size_t)(16 * ((qlen + 15) / 16) + 16));
+	std::vector<uint8_t> rowmax((size_t)tlen + 8);
+	const arx::U8Res r = arx::u8_align(q, qlen, t, tlen, xtra, row.data(), 1, rowmax.data(), exact_f != 0);
+	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
+}
+
 // test entry: the rescue pre-filter alone (tests/test_sw_prefilter.py checks it against the oracle's ksw_align2)
 extern "C" int arx_test_sw_prefilter(const uint8_t *q, int qlen, const uint8_t *t, int tlen) { return arx::sw_prefilter_serial(q, qlen, t, tlen) ? 1 : 0; }
 

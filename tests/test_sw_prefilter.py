@@ -74,3 +74,76 @@ def test_filtered_tasks_score_below_min_seed_len(built):
         n_high += score >= 19
     assert n_high > 1500 and n_low > 1500          # both sides of the threshold are exercised ...
     assert n_filtered > 0.7 * n_low                 # ... and the filter catches most of what it may catch
+
+
+def _sw_pairs(rng, n):
+    """(query, target) pairs that make F work: indels of every length on both sides, low-complexity runs with exact ties, two copies of the query,
+    unrelated sequence, Ns -- queries of 20..249 bases, windows of up to 700."""
+    out = []
+    for i in range(n):
+        ql = int(rng.integers(20, 250))
+        q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+        kind = i % 6
+        if kind == 0:
+            t = q.copy()
+            for _ in range(int(rng.integers(1, 4))):                                   # several indels
+                p = int(rng.integers(0, len(t)))
+                L = int(rng.integers(1, 25))
+                t = np.concatenate([t[:p], rng.integers(0, 4, size=L, dtype=np.uint8), t[p:]]) if rng.random() < 0.5 else np.concatenate([t[:p], t[min(len(t), p + L):]])
+            t = np.concatenate([rng.integers(0, 4, size=int(rng.integers(0, 150)), dtype=np.uint8), t, rng.integers(0, 4, size=int(rng.integers(0, 150)), dtype=np.uint8)])
+        elif kind == 1:
+            unit = rng.integers(0, 4, size=int(rng.integers(1, 5)), dtype=np.uint8)
+            q = np.tile(unit, 260)[:ql]
+            t = np.tile(unit, 800)[:int(rng.integers(ql, min(700, 3 * ql)))].copy()
+            for _ in range(int(rng.integers(0, 4))):
+                t[int(rng.integers(0, len(t)))] ^= 1
+        elif kind == 2:
+            c2 = q.copy()
+            m = rng.random(ql) < 0.04
+            c2[m] = rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)
+            t = np.concatenate([q[: ql // 2], rng.integers(0, 4, size=int(rng.integers(1, 40)), dtype=np.uint8), q[ql // 2:], rng.integers(0, 4, size=int(rng.integers(5, 90)), dtype=np.uint8), c2])
+        elif kind == 3:
+            t = rng.integers(0, 4, size=int(rng.integers(30, 700)), dtype=np.uint8)
+        elif kind == 4:
+            t = np.concatenate([q, rng.integers(0, 4, size=30, dtype=np.uint8)])
+            t[rng.integers(0, len(t), size=3)] = 4
+            q = q.copy(); q[int(rng.integers(0, ql))] = 4
+        else:
+            m = rng.random(ql) < 0.12
+            t = q.copy(); t[m] = rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)
+            t = np.concatenate([rng.integers(0, 4, size=40, dtype=np.uint8), t])
+        out.append((q, np.ascontiguousarray(t[:700], dtype=np.uint8)))
+    return out
+
+
+def test_plain_recurrence_for_f_gives_what_the_lazy_loop_gives(built):
+    """The rescue kernel computes a row's F by a prefix scan (hip_sw_coop.h) where ksw_u8 runs its lazy-F loop after a striped main pass that
+    restarts F at every stripe and feeds E the H from before the loop.  The H values -- hence score, ends, second-best score and its end, starts
+    -- are the same: checked here with the plain recurrence (dev_sw.h u8_pass, exact_f) against the restatement of the reference's procedure on
+    pairs built to exercise F (and against the golden vectors the compiled reference wrote)."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    lib = C.CDLL(SIM)
+    z = np.load(os.path.join(workloads.GOLDEN_DIR, "bwa_path_v1.npz"))
+    o = oradrv.Oracle(workloads.unpack_index(z, tempfile.mkdtemp(prefix="arx_swx_")))
+
+    lib.arx_test_sw_exact_f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+    def dev(q, t, xtra, exact):
+        out = np.zeros(7, dtype=np.int32)
+        lib.arx_test_sw_exact_f(q.ctypes.data, len(q), t.ctypes.data, len(t), xtra, exact, out.ctypes.data)
+        return out
+
+    qo = np.concatenate([[0], np.cumsum(z["sw_qlen"])]); to = np.concatenate([[0], np.cumsum(z["sw_tlen"])])
+    for i in range(len(z["sw_qlen"])):                                                   # the reference's own outputs
+        q = np.ascontiguousarray(z["sw_q"][qo[i]:qo[i + 1]]); t = np.ascontiguousarray(z["sw_t"][to[i]:to[i + 1]])
+        assert (dev(q, t, XTRA, 1) == z["sw_aln_out"][i]).all(), i
+    rng = np.random.default_rng(4242)
+    n_gapped = 0
+    for i, (q, t) in enumerate(_sw_pairs(rng, 420)):
+        for xtra in (XTRA, 0x40000 | 0x10000 | 30):
+            exp = o.ksw_align2(q, t, xtra)
+            assert (dev(q, t, xtra, 0) == exp).all(), ("lazy", i)
+            assert (dev(q, t, xtra, 1) == exp).all(), ("plain", i, dev(q, t, xtra, 1), exp)
+        n_gapped += int(exp[0] >= 19)
+    assert n_gapped > 200
