@@ -310,6 +310,53 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		// the row's scores + 4 as bytes: query codes 0..3 in the low word (match 5, mismatch 0; a target N: 3 everywhere), N -> 3 and padding -> 4 in the high word
 		const uint32_t Wlo = tb > 3 ? 0x03030303u : 5u << (8 * tb), Whi = 0x0403u;
 		int h = pk_rot_up(hlast, l), f = 0, mx = 0;
+		if (ARX_SW_SCANF) { // F by a prefix scan over the 32 segments (see the unpacked pass): both halves scan side by side, then the high halves
+			// (segments 16 .. 31) take what leaves segment 15, less the segments in between
+#pragma unroll
+			for (int j = 0; j < S2; ++j) {
+				const bool valid = j < slen;
+				const int s = (int)__builtin_amdgcn_perm(Whi, Wlo, QS[j]);
+				const int G = pk_max(pk_sub(pk_add(h, s), C4), E[j]);
+				Hout[j] = G;
+				const int fn = pk_max(pk_max(pk_sub(f, C1), pk_sub(G, C7)), 0);
+				f = valid ? fn : f;
+				h = Hin[j];
+			}
+			const int sl2 = slen | slen << 16;
+			int x = f, y;
+			y = pk_sub(dpp_rowz<DPP_ROW_SHR + 1>(x), sl2); x = pk_max(x, y);
+			y = pk_sub(dpp_rowz<DPP_ROW_SHR + 2>(x), 2 * sl2); x = pk_max(x, y);
+			y = pk_sub(dpp_rowz<DPP_ROW_SHR + 4>(x), 4 * sl2); x = pk_max(x, y);
+			y = pk_sub(dpp_rowz<DPP_ROW_SHR + 8>(x), 8 * sl2); x = pk_max(x, y);
+			const int T = (int)(short)(__shfl(x, (__lane_id() & 48) | 15, 64) & 0xffff); // what leaves segment 15
+			const int ex = dpp_rowz<DPP_ROW_SHR + 1>(x);                                   // what the segments of the own half send in (nothing in lane 0)
+			int th = T - l * slen; th = th > 0 ? th : 0;
+			f = pk_max(ex, (int)((uint32_t)th << 16));
+#pragma unroll
+			for (int j = 0; j < S2; ++j) {
+				const bool valid = j < slen;
+				const int hh = pk_max(Hout[j], f);
+				Hout[j] = hh;
+				const int h7 = pk_sub(hh, C7);
+				E[j] = pk_max(pk_max(pk_sub(E[j], C1), h7), 0);
+				const int fn = pk_max(pk_max(pk_sub(f, C1), h7), 0);
+				f = valid ? fn : f;
+				mx = pk_max(mx, valid ? (FULL ? hh : hh & KM[j]) : 0);
+			}
+			const int imax = pk_g16_max(mx);
+			if (minsc < 0x10000 && l == 0) rowmax[i] = (uint8_t)imax;
+			++rows;
+			bool brk = false;
+			if (imax > gmax) {
+				gmax = imax; te = i;
+#pragma unroll
+				for (int j = 0; j < S2; ++j) HM[j] = Hout[j];
+				if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
+			}
+#pragma unroll
+			for (int j = 0; j < S2; ++j) if (j == slen - 1) hlast = Hout[j];
+			return brk;
+		}
 #pragma unroll
 		for (int j = 0; j < S2; ++j) {
 			const bool valid = j < slen;
@@ -403,7 +450,7 @@ __device__ U8Res sw_u8_pass_p16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 }
 
 #ifndef ARX_SW_PACKED
-#define ARX_SW_PACKED 0 // 1: the packed pass (exact, measured slower: 32 segments double the boundaries the lazy-F loop has to carry F across, 15.7 -> 17.1 ms)
+#define ARX_SW_PACKED 1 // 0: one cell per register (A/B).  (With the lazy-F loop the packed pass was SLOWER, 15.7 -> 17.1 ms: 32 segments double the boundaries that loop carries F across; with the scan it is the faster one)
 #endif
 template <int SL>
 __device__ __forceinline__ U8Res sw_u8_pass_g16(const SwSeqs &sq, int qlen, int tlen, int xtra, uint8_t *rowmax)
