@@ -98,7 +98,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		const uint32_t W = u8_score_word(sq.t(i));
 		int h = g16_shift_up(hlast, l), f = 0, mx = 0;
 		if (I16) h = lane_on ? h : 0;
-		if (ARX_SW_SCANF && !I16) {
+		if (ARX_SW_SCANF) {
 			// F without the lazy loop (end of round 3).  f(j + 1) = max(f(j) - 1, H(j) - 7) with H = max(G, f), G = max(M', E): the f - 7 inside H - 7
 			// never beats f - 1, so F is the max-plus prefix of G alone -- the lane's own cells (sweep 1: what they send on as F, starting from
 			// nothing), the segments before it (a four-step scan over the 16 lanes, each segment passed costs its length), then the same chain
@@ -137,7 +137,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 				const int f1 = f - 1, fm = f1 > h7 ? f1 : h7;
 				const int fn = fm > 0 ? fm : 0;
 				f = valid ? fn : f;
-				const int hm = valid ? hh : 0;
+				const int hm = (valid && lane_on) ? hh : 0; // (16-bit element size: the eight lanes beyond the reference's stripes hold nothing it has)
 				mx = mx > hm ? mx : hm;
 			}
 			const int imax = g16_max(mx);
@@ -148,7 +148,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 				gmax = imax; te = i;
 #pragma unroll
 				for (int j = 0; j < SL; ++j) HM[j] = Hout[j];
-				if (gmax + 4 >= 255 || gmax >= endsc) brk = true;
+				if ((!I16 && gmax + 4 >= 255) || gmax >= endsc) brk = true;
 			}
 #pragma unroll
 			for (int j = 0; j < SL; ++j) if (j == slen - 1) hlast = Hout[j];
@@ -232,7 +232,7 @@ __device__ U8Res sw_u8_pass_g16_impl(const SwSeqs &sq, int qlen, int tlen, int x
 		int bv = -1, bq = 0x7fffffff; // this lane's best saved value and the smallest query position holding it
 #pragma unroll
 		for (int j = 0; j < SL; ++j) {
-			if (j < slen) {
+			if (j < slen && lane_on) {
 				int v = HM[j], qp = j + l * slen;
 				if (v > bv) { bv = v; bq = qp; }
 			}
