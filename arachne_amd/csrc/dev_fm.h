@@ -68,6 +68,21 @@ ARX_DEVI void block_occ4_w(const OccHead &h, uint64_t w, int n, uint64_t cnt[4])
 	cnt[3] = head_cum(h, 3) + (ck >> 24) + p3;
 }
 ARX_DEVI void block_occ4(const uint32_t *blk, const OccHead &h, int n, uint64_t cnt[4]) { block_occ4_w(h, load_quarter(blk, (n - 1) >> 5), n, cnt); }
+// The same counts modulo 2^32, and what the block itself adds to each (at most 128) -- all an extension needs but for ONE symbol: the sizes of
+// the four children are differences of two such counts and lie below 2^32 (an interval never holds more rows than the text has symbols of one
+// kind on both strands), so they are exact in 32 bits; only the new interval's own row wants the 40-bit count (ext_finish).
+ARX_DEVI void block_occ4_lo(const OccHead &h, uint64_t w, int n, uint32_t cnt[4], uint32_t add[4])
+{
+	const int q = (n - 1) >> 5, nj = n - 32 * q; // nj in 1..32
+	const uint64_t keep = ~0ull << (64 - 2 * nj);
+	const uint64_t lo = w & 0x5555555555555555ull & keep, hi = (w >> 1) & 0x5555555555555555ull & keep;
+	const uint32_t p3 = (uint32_t)__builtin_popcountll(hi & lo);
+	const uint32_t c2 = (uint32_t)__builtin_popcountll(hi) - p3, c1 = (uint32_t)__builtin_popcountll(lo) - p3;
+	const uint32_t c0 = (uint32_t)nj - c1 - c2 - p3;
+	const uint32_t ck = head_ck(h, q);
+	add[0] = (ck & 0xff) + c0; add[1] = ((ck >> 8) & 0xff) + c1; add[2] = ((ck >> 16) & 0xff) + c2; add[3] = (ck >> 24) + p3;
+	cnt[0] = h.lo.x + add[0]; cnt[1] = h.lo.y + add[1]; cnt[2] = h.lo.z + add[2]; cnt[3] = h.lo.w + add[3];
+}
 
 // bwt_occ4 (bwt.c:169-187): counts in B[0..k] of the $-removed BWT.  Touches exactly one 64-byte block.
 ARX_DEVI void occ4(const IndexView &ix, uint64_t k, uint64_t cnt[4])
@@ -147,22 +162,40 @@ ARX_DEVI void ext_issue(const IndexView &ix, const Biv &ik, int is_back, bool on
 	L.hk = load_head(bk); L.wk = load_quarter(bk, L.nk ? (L.nk - 1) >> 5 : 0);
 	L.hl = load_head(bl); L.wl = load_quarter(bl, L.nl ? (L.nl - 1) >> 5 : 0);
 }
+ARX_DEVI uint32_t sel4u(const uint32_t v[4], int c) { return c == 0 ? v[0] : c == 1 ? v[1] : c == 2 ? v[2] : v[3]; }
+// every symbol occurs fewer than 2^32 times in the text (both strands): then no interval holds 2^32 rows and the sizes of an extension's children
+// are exact as 32-bit differences (GRCh38: 1.8 G at most); a uniform test on the index header, the general form stays for larger texts
+ARX_DEVI bool occ_counts_fit32(const IndexView &ix) { return (((ix.L2[1] - ix.L2[0]) | (ix.L2[2] - ix.L2[1]) | (ix.L2[3] - ix.L2[2]) | (ix.L2[4] - ix.L2[3])) >> 32) == 0; }
+template <bool FIT32 = false> // FIT32: the caller has checked occ_counts_fit32() (a kernel compiled for it: both forms in one kernel cost it a wavefront per SIMD)
 ARX_DEVI Biv ext_finish(const IndexView &ix, const Biv &ik, int is_back, int c, const ExtLoad &L)
 {
 	const uint64_t a = is_back ? ik.k : ik.l, b = is_back ? ik.l : ik.k;
-	uint64_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0};
-	if (L.nk) block_occ4_w(L.hk, L.wk, L.nk, tk);
-	if (L.nl) block_occ4_w(L.hl, L.wl, L.nl, tl);
-	const uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1];
 	uint64_t x = b + (a <= ix.primary && a + ik.s - 1 >= ix.primary);
-	if (c < 3) x += s3;
-	if (c < 2) x += s2;
-	if (c < 1) x += s1;
-	Biv ok;
-	const uint64_t tkc = sel4(tk, c), tlc = sel4(tl, c);
 	const uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
-	const uint64_t na = l2c + 1 + tkc;
-	ok.s = tlc - tkc;
+	Biv ok;
+	uint64_t na;
+	if (FIT32) {
+		// counts modulo 2^32 for the four symbols at both ends: the children's sizes are their differences; the 40-bit count is put together
+		// for symbol c at the lower end only
+		uint32_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0}, ak[4] = {0, 0, 0, 0}, al[4];
+		if (L.nk) block_occ4_lo(L.hk, L.wk, L.nk, tk, ak);
+		if (L.nl) block_occ4_lo(L.hl, L.wl, L.nl, tl, al);
+		const uint32_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1];
+		x += (uint64_t)(c < 3 ? s3 : 0u) + (uint64_t)(c < 2 ? s2 : 0u) + (uint64_t)(c < 1 ? s1 : 0u); // (three sizes may pass 2^32 together)
+		na = l2c + 1 + (L.nk ? head_cum(L.hk, c) + sel4u(ak, c) : 0);
+		ok.s = (uint64_t)(uint32_t)(sel4u(tl, c) - sel4u(tk, c));
+	} else {
+		uint64_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0};
+		if (L.nk) block_occ4_w(L.hk, L.wk, L.nk, tk);
+		if (L.nl) block_occ4_w(L.hl, L.wl, L.nl, tl);
+		const uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1];
+		if (c < 3) x += s3;
+		if (c < 2) x += s2;
+		if (c < 1) x += s1;
+		const uint64_t tkc = sel4(tk, c), tlc = sel4(tl, c);
+		na = l2c + 1 + tkc;
+		ok.s = tlc - tkc;
+	}
 	if (is_back) { ok.k = na; ok.l = x; } else { ok.l = na; ok.k = x; }
 	ok.info = 0;
 	return ok;

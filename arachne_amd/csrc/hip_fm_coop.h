@@ -591,7 +591,7 @@ static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd2(SeedKArgs
 // idle lane): at GRCh38 size a forward list has an entry for nearly every one of the ~16 depths it takes to get to one occurrence, so more
 // than half of the first pass's lists are 17-20 entries long -- just too long for a quarter of a wavefront, and half a wavefront leaves most
 // of its lanes empty from the first row on.
-template <int GL>
+template <int GL, bool FIT32>
 __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_t *list, const int32_t *n_list, int32_t *counter, int chunk, uint8_t *heavy_flag)
 {
 	constexpr int NG = 64 / GL, NW = (33 + GL - 1) / GL; // groups per wave; row words a lane copies (a row has at most 33 words)
@@ -673,7 +673,7 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 		__builtin_amdgcn_sched_barrier(0);
 		// D. (the first use waits)  E. consume
 		Biv ok = Biv();
-		if (ext) ok = ext_finish(A.ix, ent, 1, c, L);
+		if (ext) ok = ext_finish<FIT32>(A.ix, ent, 1, c, L);
 		const bool keep = ext && ok.s >= (uint64_t)k.min_intv;
 		// ballots stay wave-wide; this group's part is cut out with masks that do not change (no shifts by the group's position)
 		const unsigned long long km = __ballot(keep) & gmask, fm = __ballot(ext && !keep) & gmask;
@@ -724,15 +724,18 @@ __device__ __forceinline__ void seed_bwd_g_body(const SeedKArgs &A, const int32_
 // One launch for the three bins: every wavefront works through the 16-lane bin, then the 32-lane bin, then the 64-lane bin, moving on
 // as soon as a bin has nothing left to hand out -- the end of one bin overlaps the start of the next instead of leaving the chip to the
 // last few groups (three launches: 2.4 + 1.95 + 0.3 ms, each with its own tail).
+// FIT32: every symbol occurs fewer than 2^32 times in the text (dev_fm.h occ_counts_fit32; the host checks the index header): the sizes of an
+// extension's children in 32 bits, the 40-bit count for one symbol only
+template <bool FIT32>
 static __global__ void __launch_bounds__(64, ARX_SEED_WPE) k_seed_bwd_g(SeedKArgs A, const int32_t *bins, int n, int32_t *cnt, uint8_t *heavy_flag)
 {
-	seed_bwd_g_body<16>(A, bins, cnt, cnt + 4, 32, heavy_flag);
+	seed_bwd_g_body<16, FIT32>(A, bins, cnt, cnt + 4, 32, heavy_flag);
 	__builtin_amdgcn_wave_barrier();
-	seed_bwd_g_body<21>(A, bins + n, cnt + 1, cnt + 5, 24, heavy_flag);
+	seed_bwd_g_body<21, FIT32>(A, bins + n, cnt + 1, cnt + 5, 24, heavy_flag);
 	__builtin_amdgcn_wave_barrier();
-	seed_bwd_g_body<32>(A, bins + 2 * (size_t)n, cnt + 2, cnt + 6, 16, heavy_flag);
+	seed_bwd_g_body<32, FIT32>(A, bins + 2 * (size_t)n, cnt + 2, cnt + 6, 16, heavy_flag);
 	__builtin_amdgcn_wave_barrier();
-	seed_bwd_g_body<64>(A, bins + 3 * (size_t)n, cnt + 3, cnt + 7, 2, heavy_flag);
+	seed_bwd_g_body<64, FIT32>(A, bins + 3 * (size_t)n, cnt + 3, cnt + 7, 2, heavy_flag);
 }
 // ---- the backward sweeps, entry-parallel (end of round 3; ARX_SEED_BWD2=3).  What bwt_smem1a's backward loop computes (bwt.c:322-348) is,
 // for every interval of the forward list on its own, how far to the left it can be extended before it holds fewer than min_intv occurrences:

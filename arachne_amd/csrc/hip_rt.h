@@ -195,6 +195,7 @@ struct HipRT {
 	int seed_bwd_mid = getenv("ARX_SEED_BWD_MID") ? atoi(getenv("ARX_SEED_BWD_MID")) : 21; // longest list of the 21-lane bin of the backward sweeps (16: none)
 	int seed_bwd_e_bpc = getenv("ARX_SEED_BWD_E_BPC") ? atoi(getenv("ARX_SEED_BWD_E_BPC")) : 32; // its resident workgroups per CU (62 VGPRs: eight wavefronts per SIMD fit)
 	int seed_bwd_e_chunk = getenv("ARX_SEED_BWD_E_CHUNK") ? atoi(getenv("ARX_SEED_BWD_E_CHUNK")) : 256; // list entries a wavefront reserves per atomic (entry-parallel sweeps)
+	bool seed_fit32 = !(getenv("ARX_SEED_FIT32") && atoi(getenv("ARX_SEED_FIT32")) == 0); // 0: the general (40-bit) arithmetic in the backward sweeps whatever the index (A/B)
 	bool text_bwd = !(getenv("ARX_TEXT_BWD") && atoi(getenv("ARX_TEXT_BWD")) == 0);
 	int seed_bwd_bpc = getenv("ARX_SEED_BWD_BPC") ? atoi(getenv("ARX_SEED_BWD_BPC")) : 20;
 	int seed_row = SEED_ROW;                                   // LDS bytes per lane for its read
@@ -453,7 +454,9 @@ struct HipRT {
 			{
 				Scope sc(*this, nm, n);
 				hipLaunchKernelGGL(k_bin_tasks, dim3((n + 255) / 256), dim3(256), 0, stream, f.P.tasks, f.t0, n, bins, bins + n, bins + 2 * (size_t)n, bins + 3 * (size_t)n, cnt, seed_bwd_mid);
-				hipLaunchKernelGGL(k_seed_bwd_g, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, n, cnt, flag);
+				const bool fit32 = seed_fit32 && (((f.ix.L2[1] - f.ix.L2[0]) | (f.ix.L2[2] - f.ix.L2[1]) | (f.ix.L2[3] - f.ix.L2[2]) | (f.ix.L2[4] - f.ix.L2[3])) >> 32) == 0;
+				if (fit32) hipLaunchKernelGGL(k_seed_bwd_g<true>, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, n, cnt, flag);
+				else hipLaunchKernelGGL(k_seed_bwd_g<false>, dim3(blocks_for(4)), dim3(64), ((4 * (size_t)seed_row + 31) & ~(size_t)31) + xch, stream, A, bins, n, cnt, flag);
 				ARX_HIP_CHECK(hipGetLastError());
 			}
 			if (getenv("ARX_SEED_HIST")) { // diagnostics: forward-list lengths of this launch's tasks

@@ -282,6 +282,32 @@ extern "C" long arx_test_text_match(unsigned seed, int iters)
 	return cases;
 }
 
+// test entry: an extension's arithmetic with the children's sizes in 32 bits (dev_fm.h ext_finish<true>, what k_seed_bwd_g<true> runs) against the
+// general 40-bit form and against extend1, on intervals of the context's index: every symbol as a start, then random walks of extensions in
+// both directions.  Returns the extensions compared (< 0: first mismatch; 0: the index does not qualify).
+extern "C" long arx_test_ext_fit32(arx_ctx *h, unsigned seed, int walks)
+{
+	using namespace arx;
+	const IndexView &ix = ((Context<SimRT> *)h)->ix;
+	if (!occ_counts_fit32(ix)) return 0;
+	uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 3);
+	auto rnd = [&](int m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (int)(x % (uint64_t)m); };
+	long n = 0;
+	for (int w = 0; w < walks; ++w) {
+		Biv ik = set_intv(ix, rnd(4));
+		for (int step = 0; step < 40 && ik.s > 0; ++step) {
+			const int back = rnd(2), c = rnd(4);
+			ExtLoad L;
+			ext_issue(ix, ik, back, true, L);
+			const Biv a = ext_finish<true>(ix, ik, back, c, L), b = ext_finish<false>(ix, ik, back, c, L), e = extend1(ix, ik, back, c);
+			++n;
+			if (a.k != b.k || a.l != b.l || a.s != b.s || a.k != e.k || a.l != e.l || a.s != e.s) return -n;
+			ik = a;
+		}
+	}
+	return n;
+}
+
 // test entry: the backward comparison of text mode (dev_fm.h text_match_back: the entry-parallel backward sweeps) against the text itself
 extern "C" long arx_test_text_match_back(unsigned seed, int iters)
 {

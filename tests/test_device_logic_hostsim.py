@@ -220,6 +220,18 @@ def test_backward_sweeps_entry_by_entry(monkeypatch, text):
     b.free(); ref.close(); o.close()
 
 
+def test_extension_with_32_bit_child_sizes(env):
+    """k_seed_bwd_g<true>'s arithmetic (dev_fm.h ext_finish<true>: the four children's sizes as 32-bit differences, the 40-bit count for one symbol)
+    against the general form and extend1 on random walks over the golden index."""
+    import ctypes as C
+    z, ref, o = env
+    lib = ref.lib
+    lib.arx_test_ext_fit32.restype = C.c_long
+    lib.arx_test_ext_fit32.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+    n = lib.arx_test_ext_fit32(ref.h, 11, 4000)
+    assert n > 30000, n
+
+
 def test_index_info(env):
     z, ref, o = env
     info = ref.index_info()
