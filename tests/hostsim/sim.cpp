@@ -116,7 +116,7 @@ struct SimRT {
 	bool dedup_heavy_ok() const { return getenv("ARX_SIM_DEDUP_HEAVY") != nullptr; }
 	template <class F> void run_dedup_heavy(const char *nm, int, const F &f) { tm[nm].calls++; for (int i = 0; i < *f.n_heavy; ++i) f.one_thread(f.heavy_list[i], f.eh); }
 	bool chain_heavy_ok() const { return getenv("ARX_SIM_CHAIN_HEAVY") != nullptr; }
-	template <class F> void run_chain_heavy(const char *nm, int, const F &f) { F g = f; g.heavy_list = nullptr; tm[nm].calls++; for (int i = 0; i < *f.n_heavy; ++i) g(f.heavy_list[i], 0); }
+	template <class F> void run_chain_heavy(const char *nm, int, const F &f) { F g = f; g.heavy_list = nullptr; g.mid_list = nullptr; tm[nm].calls++; for (int i = 0; i < *f.n_heavy; ++i) g(f.heavy_list[i], 0); }
 	template <class F> void run_rescue_heavy(const char *nm, int n, const int32_t *list, const F &f) { F g = f; g.heavy = nullptr; tm[nm].calls++; for (int i = 0; i < n; ++i) g(list[i], 0); }
 	std::vector<uint8_t> stage_mem;
 	void *stage(size_t bytes) { stage_mem.assign(bytes + 8, 0xCD); return stage_mem.data(); }
