@@ -4,8 +4,11 @@
 // 16 byte lanes of an XMM register; here the 16 stripes live in 16 adjacent GPU lanes (one DPP row), four alignments
 // per 64-wide wavefront.  H/E/Hmax stay in VGPRs (slen <= SL values per lane, loops fully unrolled), the byte shift of
 // `_mm_slli_si128(x, 1)` is a lane shift inside the row, `_mm_movemask_epi8` is a ballot, the horizontal max a 4-step
-// butterfly.  Cell order, saturation, lazy-F early exit and tie rules are those of the reference, so the results are
-// bit-identical to u8_align() in dev_sw.h (the one-thread-per-alignment form the parity tests pin).
+// butterfly.  Saturation and tie rules are those of the reference and the results are bit-identical to u8_align() in dev_sw.h (the
+// one-thread-per-alignment form the parity tests pin) -- but since the end of round 3 the row is no longer computed the reference's way:
+// F comes from a prefix scan over the lanes instead of the lazy-F loop (ARX_SW_SCANF), and the 8-bit element size runs on packed 16-bit
+// pairs, 32 segments of the query in the 16 lanes (ARX_SW_PACKED); the H values are the same function of the two sequences either way
+// (tests/test_sw_prefilter.py on the host double, the GPU suite and the fuzz runs against the compiled reference).
 #pragma once
 #include "arx_dev.h"
 #include "dev_sw.h"
