@@ -781,7 +781,7 @@ __device__ ExtRes ext2_b16(const IndexView &ix, const uint8_t *bases, const ExtT
 	const int qlen = t.qlen, tlen = t.tlen, h0 = t.h0;
 	const int c0 = l * C;
 	const int NEG = -0x40000000;
-	int H[C], E[C], Mv[C], M7[C], hv[C], pref[C];
+	int H[C], E[C], Mv[C], pref[C];
 	uint32_t SCW[C]; // nibble tb of SCW[u]: score of column c0 + u against target base tb, plus 4
 #pragma unroll
 	for (int u = 0; u < C; ++u) {
@@ -827,9 +827,9 @@ __device__ ExtRes ext2_b16(const IndexView &ix, const uint8_t *bases, const ExtT
 			const int sc4 = (int)((SCW[u] >> tb4) & 15u);
 			const int hs = H[u] + sc4 - 4, hz = H[u] << 15;
 			const int M = hs < hz ? hs : hz;
-			Mv[u] = M; M7[u] = M - 7;
+			Mv[u] = M;
 			pref[u] = pm;
-			int key = M7[u] + (u + 1); key = key > u + 1 ? key : u + 1;
+			int key = M + (u + 1 - 7); key = key > u + 1 ? key : u + 1;
 			pm = pm > key ? pm : key;
 		}
 		int x = pm + c0, y;
@@ -839,31 +839,33 @@ __device__ ExtRes ext2_b16(const IndexView &ix, const uint8_t *bases, const ExtT
 		y = dpp_rowz<DPP_ROW_SHR + 8>(x); x = x > y ? x : y;
 		const int ex = dpp_rowz<DPP_ROW_SHR + 1>(x) - c0; // exclusive prefix maximum relative to this lane's first column: >= 0 (the lane before ends on a key >= its base + C), 0 in lane 0
 		// sweep 2: F, H, E; the lane's row maximum as (h << 8 | u)
-		int best = 0;
+		int best = 0, hlast = 0;
 #pragma unroll
 		for (int u = 0; u < C; ++u) {
 			const int pmx = ex > pref[u] ? ex : pref[u];
 			const int F = pmx - u; // (max of t(k) + k + 1) - 1 - (j - 1); 0 - u <= 0 where no column precedes: like the serial chain's f = 0 it never beats M, E >= 0
 			int h = Mv[u] > E[u] ? Mv[u] : E[u];
 			h = h > F ? h : F;
-			hv[u] = h;
-			int e = E[u] - 1; e = e > M7[u] ? e : M7[u]; e = e > 0 ? e : 0;
+			const int m7 = Mv[u] - 7;
+			int e = E[u] - 1; e = e > m7 ? e : m7; e = e > 0 ? e : 0;
 			const bool act = nact > u;
 			E[u] = act ? e : E[u];
 			const int pk = (act ? h : 0) << 8 | u;
 			best = best > pk ? best : pk;
+			// eh[j + 1].h <- H(i, j) for j + 1 <= end (H[u + 1] was consumed by sweep 1: written in place, no copy of the row kept)
+			if (u + 1 < C) H[u + 1 < C ? u + 1 : 0] = act ? h : H[u + 1 < C ? u + 1 : 0];
+			else hlast = h;
 		}
-		// sweep 3: eh[j].h <- H(i, j-1) for beg < j <= end, eh[end].e <- 0; one bit per column for the zero scan
+		// sweep 3: the lane's first column takes the last one of the lane before; eh[end].e <- 0; one bit per column for the zero scan
 		const int h1lane = l == 0 ? h1init : 0;
-		int from_prev = dpp_rowz<DPP_ROW_SHR + 1>(hv[C - 1]);
+		int from_prev = dpp_rowz<DPP_ROW_SHR + 1>(hlast);
 		from_prev = from_prev > h1lane ? from_prev : h1lane; // lane 0 (column 0): h1; scores are >= 0
+		H[0] = nact >= 0 ? from_prev : H[0];
 		uint32_t zm = 0;
 		int own = -1;
 #pragma unroll
 		for (int u = 0; u < C; ++u) {
-			const int prev = u == 0 ? from_prev : hv[u > 0 ? u - 1 : 0];
-			const int hn = nact >= u ? prev : H[u];
-			H[u] = hn;
+			const int hn = H[u];
 			const int en = nact == u ? 0 : E[u];
 			E[u] = en;
 			const uint32_t nz = (uint32_t)(hn | en);
@@ -934,8 +936,11 @@ __device__ __forceinline__ void extend_class_b16(const IndexView &ix, const uint
 	}
 }
 
+#ifndef ARX_EXT_WAVES_ATTR
+#define ARX_EXT_WAVES_ATTR
+#endif
 template <int C, bool OLD>
-__global__ void __launch_bounds__(64) k_extend_b16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
+__global__ void __launch_bounds__(64) ARX_EXT_WAVES_ATTR k_extend_b16(IndexView ix, const uint8_t *bases, const ExtTask *tasks, ExtRes *res, int n)
 {
 	__shared__ uint8_t target_lds[4][EXT_T_CAP];
 	extend_class_b16<C, OLD>(ix, bases, tasks, res, n, blockIdx.x, gridDim.x, target_lds[threadIdx.x >> 4]);
