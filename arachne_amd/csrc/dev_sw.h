@@ -354,6 +354,49 @@ ARX_DEV int global2_task(const IndexView &ix, const SegView &sv, int qlen, int t
 	return score;
 }
 
+// Score and mismatch count of a gap-free region: the l pairs (q[j], T[rb + j]), T = forward strand + its reverse complement, whichever way
+// bwa_gen_cigar2 walks them (bwa.c:135-149, 169-199).  Four pairs per step: the read's four bytes as one (unaligned) word, squeezed to 2-bit
+// codes with the ambiguity bit kept aside; the packed strand's byte slides along (one new byte per step: upwards on the forward strand,
+// downwards and complemented on the reverse strand).  The target never holds an ambiguous base (the packed strand has two bits per base),
+// so a pair scores OPT_A (equal), -1 (read base > 3) or -OPT_B.
+ARX_DEVI void gapfree_counts(const IndexView &ix, const uint8_t *q, int64_t rb, int l, int *score, int *n_mm_out)
+{
+	int n_mm = 0, n_amb = 0, j = 0;
+	const bool rev = rb >= ix.l_pac;
+	if (l >= 4) {
+		const int64_t p0 = rev ? (ix.l_pac << 1) - 1 - rb : rb; // position on the packed strand of pair 0; pair j: p0 + j (forward), p0 - j (reverse)
+		const int o = (int)(p0 & 3);
+		const int64_t b_lim = rev ? (p0 - (l - 1)) >> 2 : (p0 + (l - 1)) >> 2; // last byte the region touches
+		int64_t b = p0 >> 2;
+		uint32_t cur = ix.pac[b], nxt;
+		if (!rev) { b = b + 1 < b_lim ? b + 1 : b_lim; nxt = ix.pac[b]; }
+		else { b = b - 1 > b_lim ? b - 1 : b_lim; nxt = ix.pac[b]; }
+		for (; j + 4 <= l; j += 4) {
+			uint32_t qw;
+			__builtin_memcpy(&qw, q + j, 4);
+			const uint32_t amb = ((qw >> 2) & 1u) | ((qw >> 8) & 4u) | ((qw >> 14) & 0x10u) | ((qw >> 20) & 0x40u); // bit 2m: read base m is > 3
+			uint32_t t8, q8;
+			if (!rev) { // bases p .. p + 3 from the top down in (cur, nxt): pair m in bits 7 - 2m, 6 - 2m
+				t8 = (((cur << 8) | nxt) >> (8 - 2 * o)) & 0xffu;
+				q8 = ((qw & 3u) << 6) | ((qw >> 4) & 0x30u) | ((qw >> 14) & 0xcu) | ((qw >> 24) & 3u);
+			} else { // bases p, p - 1, .. p - 3 complemented: pair m in bits 2m + 1, 2m
+				t8 = ((((nxt << 8) | cur) >> (6 - 2 * o)) & 0xffu) ^ 0xffu;
+				q8 = (qw & 3u) | ((qw >> 6) & 0xcu) | ((qw >> 12) & 0x30u) | ((qw >> 18) & 0xc0u);
+			}
+			const uint32_t x = t8 ^ q8;
+			const uint32_t d = ((x | (x >> 1)) & 0x55u) | (rev ? amb : ((amb & 1u) << 6) | ((amb & 4u) << 2) | ((amb >> 2) & 4u) | ((amb >> 6) & 1u));
+			n_mm += __builtin_popcount(d);
+			n_amb += __builtin_popcount(amb);
+			cur = nxt;
+			if (!rev) { b = b + 1 < b_lim ? b + 1 : b_lim; } else { b = b - 1 > b_lim ? b - 1 : b_lim; }
+			nxt = ix.pac[b];
+		}
+	}
+	for (; j < l; ++j) { const int t = ref_base(ix, rb + j), c = q[j]; n_mm += c != t; n_amb += c > 3; }
+	*n_mm_out = n_mm;
+	*score = (l - n_mm) * OPT_A - (n_mm - n_amb) * OPT_B - n_amb;
+}
+
 // bwa_gen_cigar2 (bwa.c:121-207) for an in-range region on one strand.  With want_cigar = false only the score is computed
 // (mem_patch_reg's use).  Returns false when the region is rejected (score untouched).
 ARX_DEV bool gen_cigar2(const IndexView &ix, int w_, const uint8_t *query, int qb, int qe, int64_t rb, int64_t re,
@@ -368,7 +411,7 @@ ARX_DEV bool gen_cigar2(const IndexView &ix, int w_, const uint8_t *query, int q
 	SegView sv{query, qb, qe, rb, re, rb >= L};
 	if (l_query == rlen && w_ == 0) { // gap-free shortcut (bwa.c:141-149); NM of the single M run (bwa.c:169-199) in the same walk
 		int s = 0, n_mm = 0;
-		for (int i = 0; i < l_query; ++i) { const int t = sv.tat(ix, i), q = sv.qat(i); s += sc_mat(t, q); n_mm += q != t; }
+gapfree_counts(ix, query + qb, rb, l_query, &s, &n_mm);
 		*score = s;
 		if (want_cigar) { cg[0] = (uint32_t)l_query << 4; *n_cigar = 1; if (cap >= 1) *NM = n_mm; }
 		return true;

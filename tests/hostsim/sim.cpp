@@ -237,6 +237,49 @@ extern "C" long arx_test_dedup_insert(unsigned seed, int iters, long *n_fast, lo
 }
 
 // test entry: text mode's word-parallel comparison (dev_fm.h text_match_chunk on a row of 4-bit codes, what the wavefront kernels run) against
+// gapfree_counts (four pairs per step on words) against the pair-by-pair walk of bwa_gen_cigar2's shortcut, on random packed strands: both
+// strands, every phase of the region's start within a byte, regions that end at either end of a strand, lengths 1 .. 260, reads that mostly
+// match with planted differences and ambiguous bases, unaligned read addresses.  Returns the cases compared (< 0: first mismatch).
+extern "C" long arx_test_gapfree(unsigned seed, int iters)
+{
+	using namespace arx;
+	uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 7);
+	auto rnd = [&](int m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (int)(x % (uint64_t)m); };
+	long cases = 0;
+	for (int it = 0; it < iters; ++it) {
+		const int64_t l_pac = 8 + rnd(it % 4 == 0 ? 40 : 900);
+		std::vector<uint8_t> store((size_t)(l_pac / 4 + 1), 0); // no spare bytes behind the strand: a read past its last byte shows under a sanitizer
+		uint8_t *pac = store.data();
+		for (int64_t p = 0; p < l_pac; ++p) pac[p >> 2] |= (uint8_t)(rnd(4) << ((~p & 3) << 1));
+		IndexView ix = IndexView();
+		ix.pac = pac; ix.l_pac = l_pac; ix.seq_len = (uint64_t)(2 * l_pac);
+		for (int rep = 0; rep < 8; ++rep) {
+			const bool rev = rnd(2) == 1;
+			int l = 1 + rnd(260); if (l > l_pac) l = (int)l_pac;
+			const int edge = rnd(4);
+			int64_t rb = edge == 0 ? 0 : edge == 1 ? l_pac - l : rnd((int)(l_pac - l + 1));
+			if (rev) rb += l_pac;
+			const int shift = rnd(4);
+			std::vector<uint8_t> q((size_t)l + 8, 9);
+			uint8_t *qp = q.data() + shift;
+			const int p_diff = rnd(3) == 0 ? 2 : 20, p_amb = rnd(3) == 0 ? 3 : 40;
+			for (int j = 0; j < l; ++j) {
+				int b = ref_base(ix, rb + j);
+				if (rnd(p_diff) == 0) b = (b + 1 + rnd(3)) & 3;
+				if (rnd(p_amb) == 0) b = 4;
+				qp[j] = (uint8_t)b;
+			}
+			int s_want = 0, mm_want = 0;
+			for (int j = 0; j < l; ++j) { const int t = ref_base(ix, rb + j), c = qp[j]; s_want += sc_mat(t, c); mm_want += c != t; }
+			int s_got = -12345, mm_got = -1;
+			gapfree_counts(ix, qp, rb, l, &s_got, &mm_got);
+			if (s_got != s_want || mm_got != mm_want) return -(cases + 1);
+			++cases;
+		}
+	}
+	return cases;
+}
+
 // the base-by-base form on random packed strands and reads: matching stretches of every length, both strands, chunks that end at the
 // strand boundary and at either end of the text, ambiguous bases, reads that end inside the chunk.  Returns the cases compared (< 0: first mismatch).
 extern "C" long arx_test_text_match(unsigned seed, int iters)

@@ -152,6 +152,18 @@ def test_dedup_insert_equals_the_general_pass_on_colliding_lists():
     assert nf.value > 5000 and ng.value > 200 and nb.value > 200, (nf.value, ng.value, nb.value)
 
 
+def test_gapfree_counts_wordwise_equals_pairwise():
+    """gapfree_counts (dev_sw.h: the NM / score walk of bwa_gen_cigar2's gap-free shortcut, bwa.c:141-149,169-199, four pairs per step)
+    against the pair-by-pair walk: both strands, every byte phase, strand ends, ambiguous read bases, unaligned reads."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(SIM)])
+    lib = C.CDLL(SIM)
+    lib.arx_test_gapfree.restype = C.c_long
+    lib.arx_test_gapfree.argtypes = [C.c_uint, C.c_int]
+    for seed in (1, 2, 3):
+        assert lib.arx_test_gapfree(seed, 20000) == 8 * 20000       # negative: index of the first mismatch
+
+
 def test_text_mode_word_compare_equals_base_by_base():
     """Text mode of the first-pass forward extensions (dev_fm.h): the 64-bases-at-a-time comparison of a 4-bit-coded read row with the packed
     reference (what the wavefront kernels run) against the base-by-base form and the text itself -- both strands, chunk ends at the strand
