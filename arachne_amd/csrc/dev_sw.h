@@ -359,9 +359,6 @@ ARX_DEV int global2_task(const IndexView &ix, const SegView &sv, int qlen, int t
 // codes with the ambiguity bit kept aside; the packed strand's byte slides along (one new byte per step: upwards on the forward strand,
 // downwards and complemented on the reverse strand).  The target never holds an ambiguous base (the packed strand has two bits per base),
 // so a pair scores OPT_A (equal), -1 (read base > 3) or -OPT_B.
-#ifndef ARX_GAPFREE_UNROLL
-#define ARX_GAPFREE_UNROLL 1
-#endif
 ARX_DEVI void gapfree_counts(const IndexView &ix, const uint8_t *q, int64_t rb, int l, int *score, int *n_mm_out)
 {
 	int n_mm = 0, n_amb = 0, j = 0;
@@ -374,7 +371,7 @@ ARX_DEVI void gapfree_counts(const IndexView &ix, const uint8_t *q, int64_t rb, 
 		uint32_t cur = ix.pac[b], nxt;
 		if (!rev) { b = b + 1 < b_lim ? b + 1 : b_lim; nxt = ix.pac[b]; }
 		else { b = b - 1 > b_lim ? b - 1 : b_lim; nxt = ix.pac[b]; }
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ARX_GAPFREE_UNROLL) // 4 / 8 measured: no gain (profiles/r03/README.md); the compiler's own choice by default
 #pragma unroll ARX_GAPFREE_UNROLL
 #endif
 		for (; j + 4 <= l; j += 4) {
